@@ -1,0 +1,420 @@
+#!/usr/bin/env python3
+"""Golden-vector generator (TEST INFRASTRUCTURE, runs only in the build container).
+
+Imports the reference's hot-path files from /root/reference *as they lie there*
+(nothing is copied), behind in-process stub modules for the three third-party
+packages that are absent here (gym, pytorch_lightning, munch), runs them on
+seeded inputs and writes the inputs + outputs as small .npz fixtures under
+tests/golden/.  Only those data files travel; the reference never does.
+
+What is exercised (reference file:line):
+  * pdegym/kuramoto/kuramoto.py:29-76   ctor / derived constants
+  * pdegym/kuramoto/kuramoto.py:78-98   step  (RK4 x cfg_steps, reward)
+  * pdegym/kuramoto/kuramoto.py:100-116 reset (seeded IC + 800-step burn-in)
+  * pdegym/kuramoto/kuramoto.py:118-129 rhs   (four periodic FD stencils)
+  * pdegym/common/transforms.py:250-279 GaussianForcing (+ inverse)
+  * pdegym/common/transforms.py:62-138  Normalize (+ inverse)
+  * pdecontrol/architectures/autoreg.py:44-101  KSAutoRegConvolutionalLSTM
+  * pdecontrol/surrogates/surrogate.py:79-133   AutoRegPDESurrogate.rollout
+  * pdecontrol/surrogates/training.py:64-130    PDETrainingModule.training_step
+
+Usage:  PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py [--skip-reset]
+"""
+import argparse
+import importlib.util
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True  # never write __pycache__ into /root/reference
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+
+# --------------------------------------------------------------------------- #
+# stub modules for absent third-party packages
+# --------------------------------------------------------------------------- #
+def _install_stubs():
+    gym = types.ModuleType("gym")
+
+    class Env:
+        def __init__(self, *a, **k):
+            pass
+
+        @property
+        def unwrapped(self):
+            return self
+
+    class Box:
+        def __init__(self, low, high, shape=None, dtype=np.float32):
+            self.low, self.high, self.shape, self.dtype = low, high, shape, dtype
+
+    spaces = types.ModuleType("gym.spaces")
+    spaces.Box = Box
+    gym.Env = Env
+    gym.spaces = spaces
+    sys.modules["gym"] = gym
+    sys.modules["gym.spaces"] = spaces
+
+    pl = types.ModuleType("pytorch_lightning")
+
+    class LightningModule(torch.nn.Module):
+        def log(self, *a, **k):
+            pass
+
+    class LightningDataModule:
+        pass
+
+    class Callback:
+        pass
+
+    pl.LightningModule = LightningModule
+    pl.LightningDataModule = LightningDataModule
+    pl.Callback = Callback
+    pl.Trainer = object
+    cb = types.ModuleType("pytorch_lightning.callbacks")
+    cb.Callback = Callback
+    pl.callbacks = cb
+    sys.modules["pytorch_lightning"] = pl
+    sys.modules["pytorch_lightning.callbacks"] = cb
+
+    munch = types.ModuleType("munch")
+    munch.munchify = lambda d: d
+    sys.modules["munch"] = munch
+
+    # bare packages so that the reference's pdegym/__init__.py (which imports a
+    # non-existent pdegym.burgers) and pdegym/kuramoto/__init__.py (which needs
+    # gym.wrappers) are NOT executed.
+    for name, path in (("pdegym", "pdegym"), ("pdegym.kuramoto", "pdegym/kuramoto"),
+                       ("pdegym.common", "pdegym/common")):
+        mod = types.ModuleType(name)
+        mod.__path__ = [os.path.join(REF, path)]
+        sys.modules[name] = mod
+    sys.path.insert(0, REF)
+
+
+def _load(name, relpath):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, relpath))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+# --------------------------------------------------------------------------- #
+# KS fixtures
+# --------------------------------------------------------------------------- #
+CONFIGS = {
+    "n64": dict(L=22.0, N=64),
+    "n256": dict(L=88.0, N=256),
+    # extra sizes for the generic (any-N) kernel; same dx = 0.34375
+    "n48": dict(L=16.5, N=48),
+    "n128": dict(L=44.0, N=128),
+}
+
+
+def ks_fixtures(ks, skip_reset):
+    out = {}
+    Env = ks.KuramotoSivashinskyEnv
+
+    # (0) derived constants of the default ctor
+    env = Env()
+    out["default_consts"] = np.array(
+        [env.L, env.N, env.dx, env.dt, env.cfg_steps, env.max_episode_steps], dtype=np.float64)
+    out["default_x"] = env.x.copy()
+    assert env.reward_func.transf.__name__ == "l2control"
+
+    for tag, cfg in CONFIGS.items():
+        env = Env(**cfg)
+        N = cfg["N"]
+        rs = np.random.RandomState(7)
+
+        # (1) forcing matrix + phi for 8 actions
+        F = env.forcing.forcing.numpy().copy()
+        actions = rs.uniform(-1, 1, size=(8, 1, 4)).astype(np.float32)
+        actions[0] = [[0.3, -0.7, 1.0, -1.0]]
+        phis = np.stack([np.squeeze(env.forcing(a)) for a in actions])
+        assert F.dtype == np.float32 and phis.dtype == np.float32
+        out[f"{tag}_F"] = F
+        out[f"{tag}_actions"] = actions
+        out[f"{tag}_phi"] = phis
+        inv = env.forcing.Inverse
+        out[f"{tag}_xpos"] = inv.xpos.numpy().copy()
+        out[f"{tag}_invF"] = inv.inv_forcing.numpy().copy()
+        out[f"{tag}_phi_inv"] = np.stack([inv(p[None, :]) for p in phis])
+
+        # (2) rhs on 16 states: random (various amplitudes), exact zeros, unit impulse
+        U = rs.uniform(-1, 1, size=(16, N)) * np.array([0.4, 1, 2, 3] * 4)[:, None]
+        U[1, ::3] = 0.0
+        U[2, :] = 0.0
+        U[2, 5] = 1.0
+        U[3, :] = -0.0
+        U[3, 7] = -1.0
+        U[4] = np.sin(2 * np.pi * np.arange(N) / N * 3)
+        P = np.stack([phis[i % 8] for i in range(16)])
+        P[5] = 0.0
+        rh = [env.rhs(u, p) for u, p in zip(U, P)]
+        out[f"{tag}_rhs_u"] = U
+        out[f"{tag}_rhs_phi"] = P
+        out[f"{tag}_rhs"] = np.stack([r[0] for r in rh])
+        out[f"{tag}_ux"] = np.stack([r[1][0] for r in rh])
+        out[f"{tag}_uxx"] = np.stack([r[1][1] for r in rh])
+        out[f"{tag}_uxxxx"] = np.stack([r[1][2] for r in rh])
+
+        # (3) batch of 8 envs: state after 1, 2, 10, 250 sub-steps; rewards
+        u0 = np.stack([np.random.RandomState(1234 + e).uniform(-0.4, 0.4, N) for e in range(8)])
+        out[f"{tag}_traj_u0"] = u0
+        for n in (1, 2, 10, 250):
+            us, rews = [], []
+            for e in range(8):
+                env_n = Env(cfg_steps=n, **cfg)
+                env_n.u = u0[e].copy()
+                env_n.timestep = 0
+                obs, rew, term, trunc, info = env_n.step(actions[e])
+                assert obs.dtype == np.float64 and obs.shape == (1, N)
+                us.append(obs[0].copy())
+                rews.append(float(rew))
+            out[f"{tag}_traj_u{n}"] = np.stack(us)
+            out[f"{tag}_traj_rew{n}"] = np.asarray(rews, dtype=np.float64)
+        # per-sub-step reward terms for env 0 over 10 sub-steps
+        env1 = Env(cfg_steps=1, **cfg)
+        env1.u = u0[0].copy()
+        env1.timestep = 0
+        terms = []
+        for _ in range(10):
+            terms.append(float(env1.step(actions[0])[1]))
+        out[f"{tag}_rew_terms"] = np.asarray(terms, dtype=np.float64)
+
+        # (3b) a second consecutive step with a different action (state carry-over)
+        env2 = Env(**cfg)
+        env2.u = u0[0].copy()
+        env2.timestep = 0
+        env2.step(actions[0])
+        obs2, rew2, _, _, info2 = env2.step(actions[1])
+        out[f"{tag}_two_steps_u"] = obs2[0].copy()
+        out[f"{tag}_two_steps_rew"] = np.float64(rew2)
+        assert info2 == {"step": 2}
+
+    # (3c) dissipation objective (reachable with objective="" only, kuramoto.py:72)
+    envd = Env(objective="")
+    assert envd.reward_func.transf.__name__ == "dissipation"
+    # ... and is broken as shipped: FuncTransform hands torch tensors to rhs(), whose
+    # scipy/numpy arithmetic then fails (TypeError).  Record that, nothing to pin.
+    envd10 = Env(objective="", cfg_steps=10)
+    envd10.u = out["n64_traj_u0"][0].copy()
+    envd10.timestep = 0
+    try:
+        envd10.step(out["n64_actions"][0])
+        out["dissipation_step_raises"] = np.int64(0)
+    except TypeError:
+        out["dissipation_step_raises"] = np.int64(1)
+
+    # (5) truncated / info["step"] across an episode boundary (short episode)
+    env = Env(Tmax=1.0, cfg_steps=50)
+    assert env.max_episode_steps == 20
+    env.u = out["n64_traj_u0"][1].copy()
+    env.timestep = 17
+    seq = []
+    for _ in range(4):
+        _, _, term, trunc, info = env.step([[0.1, 0.2, -0.3, 0.4]])
+        seq.append((int(term), int(trunc), info["step"]))
+    out["episode_seq"] = np.asarray(seq, dtype=np.int64)
+
+    # (6) overflow case: L=22, N=256, dt=1e-3 raises FloatingPointError
+    env = Env(L=22.0, N=256)
+    env.u = np.random.RandomState(0).uniform(-0.4, 0.4, 256)
+    env.timestep = 0
+    try:
+        env.step([[0.0, 0.0, 0.0, 0.0]])
+        raised = 0
+    except FloatingPointError:
+        raised = 1
+    out["overflow_raises"] = np.int64(raised)
+
+    # SURVEY known answers
+    env = Env()
+    np.random.seed(0)
+    env.u = np.random.uniform(-0.4, 0.4, 64)
+    env.timestep = 0
+    out["seed0_u0"] = env.u.copy()
+    obs, rew, _, trunc, info = env.step([[0.3, -0.7, 1.0, -1.0]])
+    out["seed0_u250"] = obs[0].copy()
+    out["seed0_rew250"] = np.float64(rew)
+
+    # (4) seeded reset (800 x 250 sub-step burn-in) -- slow (~50 s each)
+    if not skip_reset:
+        for tag, seed in (("n64", 3), ("n256", 5)):
+            env = Env(**CONFIGS[tag])
+            obs, info = env.reset(seed=seed, return_info=True)
+            out[f"{tag}_reset_seed"] = np.int64(seed)
+            out[f"{tag}_reset_u"] = obs[0].copy()
+            out[f"{tag}_reset_step"] = np.int64(info["step"])
+            rs = np.random.RandomState(seed)
+            out[f"{tag}_reset_u0"] = rs.uniform(-0.4, 0.4, CONFIGS[tag]["N"])
+            print(f"reset {tag} seed={seed} done, step={info['step']}", flush=True)
+    return out
+
+
+# --------------------------------------------------------------------------- #
+# surrogate fixtures
+# --------------------------------------------------------------------------- #
+def surrogate_fixtures(tr):
+    from pdecontrol.architectures.autoreg import KSAutoRegConvolutionalLSTM
+    from pdecontrol.surrogates.training import PDETrainingModule
+    from pdegym.common.transforms import Normalize
+
+    out = {}
+
+    def build(dscaling=None, undscaling=None):
+        torch.manual_seed(0)
+        factory = KSAutoRegConvolutionalLSTM()
+        model = factory.model()
+        surrogate = factory.surrogate(delta=0.25, dscaling=dscaling, tau=5, **model)
+        module = PDETrainingModule(
+            surrogate=surrogate, loss=torch.nn.MSELoss(reduction="none"), tstep=0.25, delta=0.25,
+            undscaling=undscaling, tau=5, tbtt=10)
+        return surrogate, module
+
+    surrogate, module = build()
+    sd = surrogate.state_dict()
+    for k, v in sd.items():
+        out["sd/" + k] = v.numpy().copy()
+    out["n_trainable"] = np.int64(sum(p.numel() for p in surrogate.parameters() if p.requires_grad))
+
+    g = torch.Generator().manual_seed(1)
+    states64 = torch.rand(64, 20, 1, 64, generator=g) * 2 - 1
+    actions64 = torch.rand(64, 20, 1, 64, generator=g) * 2 - 1
+
+    # (7a) the SURVEY known answer: B=64, T=20, identity scaling
+    res = module.training_step((states64, actions64), 0)
+    res["loss"].backward()
+    gn = torch.sqrt(sum((p.grad ** 2).sum() for p in surrogate.parameters() if p.grad is not None))
+    out["b64_loss"] = np.float64(res["loss"].item())
+    out["b64_gradnorm"] = np.float64(gn.item())
+    out["b64_hsteploss"] = res["hsteploss"].numpy().copy()
+
+    # (7b) B=8 slice with all tensors + per-parameter grads
+    surrogate, module = build()
+    s8, a8 = states64[:8].clone(), actions64[:8].clone()
+    out["b8_states"] = s8.numpy().copy()
+    out["b8_actions"] = a8.numpy().copy()
+    res = module.training_step((s8, a8), 0)
+    res["loss"].backward()
+    out["b8_loss"] = np.float64(res["loss"].item())
+    out["b8_hsteploss"] = res["hsteploss"].numpy().copy()
+    out["b8_outputs"] = res["outputs"].numpy().copy()
+    out["b8_outdeltas"] = res["outdeltas"].numpy().copy()
+    out["b8_deltas"] = res["deltas"].numpy().copy()
+    for k, p in surrogate.named_parameters():
+        if p.grad is not None:
+            out["b8_grad/" + k] = p.grad.numpy().copy()
+
+    # one Adam step (training.py:273-278) then the loss again
+    opt = module.configure_optimizers()[0][0]
+    opt.step()
+    opt.zero_grad()
+    res2 = module.training_step((s8, a8), 1)
+    out["b8_loss_after_adam"] = np.float64(res2["loss"].item())
+
+    # (8) non-trivial dscaling / undscaling (Normalize, scalar stats; mbrl.py:168)
+    norm = Normalize(aggregate=True, batched=True)
+    norm.mean = torch.full((1, 1, 1), 0.01)
+    norm.var = torch.full((1, 1, 1), 0.5)
+    norm.count = 100
+    # BatchTransform wraps it in the controller (mbrl.py:168-171)
+    from pdegym.common.transforms import BatchTransform
+    undscaling = BatchTransform(norm)
+    dscaling = undscaling.Inverse
+    surrogate, module = build(dscaling=dscaling, undscaling=undscaling)
+    res = module.training_step((s8, a8), 0)
+    res["loss"].backward()
+    out["b8n_loss"] = np.float64(res["loss"].item())
+    out["b8n_hsteploss"] = res["hsteploss"].numpy().copy()
+    out["b8n_outputs"] = res["outputs"].numpy().copy()
+    out["b8n_outdeltas"] = res["outdeltas"].numpy().copy()
+    out["b8n_deltas"] = res["deltas"].numpy().copy()
+    for k, p in surrogate.named_parameters():
+        if p.grad is not None:
+            out["b8n_grad/" + k] = p.grad.numpy().copy()
+
+    # rollout API alone, warm-up of tau states then free-running, hidden carried
+    surrogate, module = build()
+    with torch.no_grad():
+        times = 0.25 * torch.arange(10)
+        targets = 0.25 * (torch.arange(10) + 1)
+        r1 = surrogate.rollout(states=s8[:, :5], actions=a8[:, :10], times=times, targets=targets, hidden=None)
+        r2 = surrogate.rollout(states=r1.outputs[:, -1, None], actions=a8[:, 10:], times=times, targets=targets,
+                               hidden=r1.hidden)
+    out["ro1_outputs"] = r1.outputs.numpy().copy()
+    out["ro1_deltas"] = r1.deltas.numpy().copy()
+    out["ro1_inlatents"] = r1.inlatents.numpy().copy()
+    out["ro1_outlatents"] = r1.outlatents.numpy().copy()
+    out["ro1_H"] = r1.hidden[0].numpy().copy()
+    out["ro1_C"] = r1.hidden[1].numpy().copy()
+    out["ro2_outputs"] = r2.outputs.numpy().copy()
+    out["ro2_H"] = r2.hidden[0].numpy().copy()
+
+    # (9) integer index paths (surrogate.py:88-89, 126) for the call patterns in
+    #     training.py:80-82, world.py:159-161 (scalar time) and world.py:184-188
+    def index_paths(times, targets, delta=0.25):
+        times, targets = torch.as_tensor(times).reshape(-1), torch.as_tensor(targets).reshape(-1)
+        timepoints = torch.arange(times[0], times[-1] + delta, delta)
+        aidx = torch.searchsorted(times, timepoints, right=True) - 1
+        tidx = torch.round(targets / delta).to(torch.long) - 1
+        return aidx.numpy(), tidx.numpy()
+
+    for name, (ti, ta) in {
+        "train10": (0.25 * torch.arange(10), 0.25 * (torch.arange(10) + 1)),
+        "train15": (0.25 * torch.arange(15), 0.25 * (torch.arange(15) + 1)),
+        "scalar": (torch.tensor(0.0), torch.tensor(0.25)),
+        "warm5": (0.25 * torch.arange(5), torch.tensor(1.25)),
+        "coarse": (torch.tensor([0.0, 0.5, 1.0]), torch.tensor([0.5, 1.0, 1.25])),
+    }.items():
+        aidx, tidx = index_paths(ti, ta)
+        out[f"idx_{name}_times"] = np.atleast_1d(ti.numpy())
+        out[f"idx_{name}_targets"] = np.atleast_1d(ta.numpy())
+        out[f"idx_{name}_aidx"] = aidx
+        out[f"idx_{name}_tidx"] = tidx
+
+    # Normalize.update statistics (transforms.py:95-127)
+    norm = Normalize(aggregate=True, batched=True)
+    g = torch.Generator().manual_seed(5)
+    b1 = torch.randn(6, 1, 64, generator=g) * 2 + 0.3
+    b2 = torch.randn(9, 1, 64, generator=g) * 0.5 - 1.0
+    norm.update(b1)
+    norm.update(b2)
+    out["norm_b1"], out["norm_b2"] = b1.numpy(), b2.numpy()
+    out["norm_mean"], out["norm_var"] = norm.mean.numpy().copy(), norm.var.numpy().copy()
+    out["norm_count"] = np.int64(norm.count)
+    out["norm_apply"] = norm(b1).numpy().copy()
+    out["norm_inverse"] = norm.Inverse(b1).numpy().copy()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--skip-reset", action="store_true", help="skip the two ~50 s burn-in resets")
+    ap.add_argument("--only", choices=["ks", "surrogate"], default=None)
+    args = ap.parse_args()
+    if not os.path.isdir(REF):
+        sys.exit("reference not present: fixtures can only be generated in the build container")
+    _install_stubs()
+    os.makedirs(OUT, exist_ok=True)
+    if args.only in (None, "ks"):
+        ks = _load("pdegym.kuramoto.kuramoto", "pdegym/kuramoto/kuramoto.py")
+        fx = ks_fixtures(ks, args.skip_reset)
+        np.savez_compressed(os.path.join(OUT, "ks_golden.npz"), **fx)
+        print("ks_golden.npz:", len(fx), "arrays")
+    if args.only in (None, "surrogate"):
+        import pdecontrol.surrogates.training as tr
+        fx = surrogate_fixtures(tr)
+        np.savez_compressed(os.path.join(OUT, "surrogate_golden.npz"), **fx)
+        print("surrogate_golden.npz:", len(fx), "arrays")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,190 @@
+/*
+ * ks_oracle.c -- CPU restatement of the reference Kuramoto-Sivashinsky stepper.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the *checker* for the HIP stepper in
+ * model-based-pde-control_amd/csrc/.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load it; the product never does.
+ *
+ * Parity pin: every function here is checked against golden vectors produced by
+ * importing the reference itself (oracle/gen_golden.py -> tests/golden/ks_golden.npz),
+ * see tests/test_oracle_ks.py.
+ *
+ * Reference (paths relative to /root/reference):
+ *   pdegym/kuramoto/kuramoto.py:24-27    stencil tables (stored flipped, see :23)
+ *   pdegym/kuramoto/kuramoto.py:118-129  rhs()
+ *   pdegym/kuramoto/kuramoto.py:78-98    step(): reward term, classical RK4
+ *   pdegym/kuramoto/kuramoto.py:64-65    l2control reward: -(1/N) * norm(u)**2
+ *   pdegym/common/transforms.py:250-265  GaussianForcing (fp32)
+ * Third-party arithmetic restated: scipy.ndimage.convolve1d(mode="wrap")
+ *   (scipy 1.10.1 pinned by poetry.lock:1578; call sites kuramoto.py:120-125).
+ *   convolve1d flips the weights and calls correlate1d, whose C loop
+ *   (ni_filters.c, NI_Correlate1D) evaluates
+ *     symmetric kernel : out = in[0]*w[0]; for j=-h..-1: out += (in[j]+in[-j])*w[j]
+ *     general kernel   : out = in[h]*w[h]; for j=-h..h-1: out += in[j]*w[j]
+ *   with w centred.  We keep that summation order so the oracle tracks the
+ *   reference to rounding (observed: <= 1 ulp-level differences).
+ *
+ * Build: gcc -O2 -ffp-contract=off -fopenmp -shared -fPIC (oracle/Makefile).
+ */
+#include <math.h>
+#include <stddef.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define H 4 /* half width of the 9-tap tables */
+
+/* kuramoto.py:24-27, as written there (i.e. before convolve1d flips them) */
+static const double TAB_FWD[9] = {-1.0 / 4, 4.0 / 3, -3.0, 4.0, -25.0 / 12, 0, 0, 0, 0};
+static const double TAB_BWD[9] = {0, 0, 0, 0, 25.0 / 12, -4.0, 3.0, -4.0 / 3, 1.0 / 4};
+static const double TAB_D2[7] = {1.0 / 90, -3.0 / 20, 3.0 / 2, -49.0 / 18, 3.0 / 2, -3.0 / 20, 1.0 / 90};
+static const double TAB_D4[9] = {7.0 / 240, -2.0 / 5,   169.0 / 60, -122.0 / 15, 91.0 / 8,
+                                 -122.0 / 15, 169.0 / 60, -2.0 / 5,  7.0 / 240};
+
+static inline int wrap(int i, int n) {
+    i %= n;
+    return i < 0 ? i + n : i;
+}
+
+/* scipy convolve1d(mode="wrap") for an odd-length table; general (non-symmetric) path */
+static void conv_general(const double *in, int n, const double *tab, int len, double *out) {
+    int h = len / 2;
+    double w[9]; /* flipped = correlation weights, w[j+h] multiplies in[i+j] */
+    for (int j = 0; j < len; ++j) w[j] = tab[len - 1 - j];
+    for (int i = 0; i < n; ++i) {
+        double t = in[wrap(i + h, n)] * w[2 * h];
+        for (int j = -h; j < h; ++j) t += in[wrap(i + j, n)] * w[j + h];
+        out[i] = t;
+    }
+}
+
+/* symmetric fast path */
+static void conv_symmetric(const double *in, int n, const double *tab, int len, double *out) {
+    int h = len / 2;
+    for (int i = 0; i < n; ++i) {
+        double t = in[i] * tab[h];
+        for (int j = -h; j < 0; ++j) t += (in[wrap(i + j, n)] + in[wrap(i - j, n)]) * tab[j + h];
+        out[i] = t;
+    }
+}
+
+/* kuramoto.py:118-129 for one env.  Any of ux/uxx/uxxxx may be NULL. */
+static void rhs_one(const double *u, const float *phi, int n, double dx, double *rhs, double *ux,
+                    double *uxx, double *uxxxx, double *scratch /* 6*n */) {
+    double *q = scratch, *fwd = q + n, *bwd = fwd + n, *d1 = bwd + n, *d2 = d1 + n, *d4 = d2 + n;
+    for (int i = 0; i < n; ++i) q[i] = u[i] * u[i];
+    conv_general(q, n, TAB_FWD, 9, fwd);
+    conv_general(q, n, TAB_BWD, 9, bwd);
+    conv_symmetric(u, n, TAB_D2, 7, d2);
+    conv_symmetric(u, n, TAB_D4, 9, d4);
+    double dx2 = dx * dx, dx4 = pow(dx, 4.0); /* python: self.dx**2, self.dx**4 */
+    for (int i = 0; i < n; ++i) {
+        double f = fwd[i] / dx, b = bwd[i] / dx;
+        /* (u < 0) * fwd + (u >= 0) * bwd  : u == 0 (and -0.0) selects the backward stencil */
+        d1[i] = (u[i] < 0 ? 1.0 : 0.0) * f + (u[i] >= 0 ? 1.0 : 0.0) * b;
+        d2[i] = d2[i] / dx2;
+        d4[i] = d4[i] / dx4;
+        rhs[i] = ((-d4[i] - d2[i]) - 0.5 * d1[i]) + (double)phi[i];
+    }
+    if (ux) memcpy(ux, d1, sizeof(double) * n);
+    if (uxx) memcpy(uxx, d2, sizeof(double) * n);
+    if (uxxxx) memcpy(uxxxx, d4, sizeof(double) * n);
+}
+
+/* Batched rhs test hook: u [E,N] f64, phi [E,N] f32 -> rhs, ux, uxx, uxxxx [E,N] f64 */
+int ks_oracle_rhs(const double *u, const float *phi, int E, int N, double dx, double *rhs,
+                  double *ux, double *uxx, double *uxxxx) {
+    double *scratch = (double *)malloc(sizeof(double) * 6 * (size_t)N);
+    if (!scratch) return -1;
+    for (int e = 0; e < E; ++e) {
+        size_t o = (size_t)e * N;
+        rhs_one(u + o, phi + o, N, dx, rhs + o, ux ? ux + o : NULL, uxx ? uxx + o : NULL,
+                uxxxx ? uxxxx + o : NULL, scratch);
+    }
+    free(scratch);
+    return 0;
+}
+
+/* kuramoto.py:83-90 for one env: n_substeps x { reward term; RK4 }.
+ * reward_sum receives sum over sub-steps of  -(1/N) * norm(u)**2  (NOT yet / cfg_steps).
+ * ssq_sum (optional) receives the raw sum over sub-steps of sum_i u_i^2. */
+static void step_one(double *u, const float *phi, int n, double dx, double dt, long n_substeps,
+                     double *reward_sum, double *ssq_sum, double *work /* 11*n */) {
+    double *k1 = work, *k2 = k1 + n, *k3 = k2 + n, *k4 = k3 + n, *us = k4 + n, *scratch = us + n;
+    double reward = 0.0, ssq_tot = 0.0;
+    for (long s = 0; s < n_substeps; ++s) {
+        double ssq = 0.0;
+        for (int i = 0; i < n; ++i) ssq += u[i] * u[i];
+        double nrm = sqrt(ssq); /* torch.norm(obs) ** 2 */
+        reward += (-1.0) * (1.0 / n) * (nrm * nrm);
+        ssq_tot += ssq;
+        rhs_one(u, phi, n, dx, k1, NULL, NULL, NULL, scratch);
+        for (int i = 0; i < n; ++i) us[i] = u[i] + dt * k1[i] / 2.0;
+        rhs_one(us, phi, n, dx, k2, NULL, NULL, NULL, scratch);
+        for (int i = 0; i < n; ++i) us[i] = u[i] + dt * k2[i] / 2.0;
+        rhs_one(us, phi, n, dx, k3, NULL, NULL, NULL, scratch);
+        for (int i = 0; i < n; ++i) us[i] = u[i] + dt * k3[i];
+        rhs_one(us, phi, n, dx, k4, NULL, NULL, NULL, scratch);
+        for (int i = 0; i < n; ++i)
+            u[i] = u[i] + dt * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]) / 6.0;
+    }
+    if (reward_sum) *reward_sum = reward;
+    if (ssq_sum) *ssq_sum = ssq_tot;
+}
+
+/* Batched step: u [E,N] in/out, phi [E,N] f32, outputs [E].  nthreads<=1: scalar loop. */
+int ks_oracle_step(double *u, const float *phi, int E, int N, double dx, double dt,
+                   long n_substeps, double *reward_sum, double *ssq_sum, int *status,
+                   int nthreads) {
+    int fail = 0;
+#pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1) reduction(| : fail)
+    for (int e = 0; e < E; ++e) {
+        double *work = (double *)malloc(sizeof(double) * 11 * (size_t)N);
+        if (!work) {
+            fail |= 1;
+            continue;
+        }
+        size_t o = (size_t)e * N;
+        step_one(u + o, phi + o, N, dx, dt, n_substeps, reward_sum ? reward_sum + e : NULL,
+                 ssq_sum ? ssq_sum + e : NULL, work);
+        if (status) {
+            int bad = 0;
+            for (int i = 0; i < N; ++i) bad |= !isfinite(u[o + i]);
+            status[e] = bad;
+        }
+        free(work);
+    }
+    return fail ? -1 : 0;
+}
+
+/* transforms.py:250-260 in fp32: F[j,i] = exp(-(x_i - L*Xi_j)^2 / (2 sigma^2)) / sqrt(2 pi sigma)
+ * x = np.linspace(0, L - L/N, N, dtype=float32) (kuramoto.py:56): computed in f64, cast to f32.
+ * torch's vectorised expf may differ from libm expf by 1 ulp: compare with a 2-ulp tolerance. */
+int ks_oracle_forcing(double L, int N, double sigma, const double *Xi, int n_act, float *F) {
+    double stop = L - L / N, step = N > 1 ? stop / (N - 1) : 0.0;
+    float two_s2 = (float)(2.0 * sigma * sigma);
+    float norm = (float)sqrt(2.0 * M_PI * sigma);
+    for (int j = 0; j < n_act; ++j) {
+        float xi = (float)L * (float)Xi[j];
+        for (int i = 0; i < N; ++i) {
+            float x = (float)(i * step);
+            if (i == N - 1 && N > 1) x = (float)stop;
+            float d = x - xi;
+            float g = expf(-(d * d) / two_s2);
+            F[(size_t)j * N + i] = g / norm;
+        }
+    }
+    return 0;
+}
+
+/* phi = actions @ F in fp32 (transforms.py:262-265): actions [E,n_act], F [n_act,N] -> [E,N].
+ * Summation order k = 0..n_act-1 with separate multiply and add (no FMA); BLAS kernels may
+ * fuse/reorder, so compare with an fp32-ulp-level tolerance. */
+int ks_oracle_phi(const float *actions, const float *F, int E, int n_act, int N, float *phi) {
+    for (int e = 0; e < E; ++e)
+        for (int i = 0; i < N; ++i) {
+            float acc = 0.0f;
+            for (int k = 0; k < n_act; ++k) acc += actions[(size_t)e * n_act + k] * F[(size_t)k * N + i];
+            phi[(size_t)e * N + i] = acc;
+        }
+    return 0;
+}
