@@ -1,0 +1,484 @@
+// ks_capi.hip -- the C ABI of libkspde.so (declared in include/kspde.h).
+//
+// Host-side only: handle bookkeeping, buffer ownership, layout choice and launches.  There is
+// deliberately no CPU implementation behind these entry points: without a HIP device every call
+// fails with KS_ERR_NO_DEVICE / KS_ERR_HIP.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "../../include/kspde.h"
+#include "ks_internal.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define KS_HIP(call)                                                                        \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail(KS_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),  \
+                        __FILE__, __LINE__);                                                \
+    } while (0)
+
+}  // namespace
+
+struct ks_handle {
+    int device = 0;
+    int E = 0, N = 0;
+    double L = 0, dt = 0, dx = 0;
+    int mode = KS_MODE_FAST;
+    int variant = KS_VARIANT_AUTO;
+    int block_threads = 0;
+    int n_act = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    // device buffers
+    double* d_u = nullptr;      // [E,N]
+    float* d_phi = nullptr;     // [E,N] staging for host phi
+    float* d_act = nullptr;     // [E,n_act]
+    float* d_F = nullptr;       // [n_act,N]
+    float* d_obs = nullptr;     // [E,N]
+    double* d_ssq = nullptr;    // [E]
+    int* d_status = nullptr;    // [E]
+    int* d_ids = nullptr;       // [E]
+    double* d_rows = nullptr;   // [E,N] staging for ks_set_state_rows / ks_rhs
+    unsigned* d_flag = nullptr; // selftest
+    int num_cus = 256;
+};
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+void fill_args(const ks_handle* h, ks::StepArgs& a) {
+    std::memset(&a, 0, sizeof(a));
+    const double dx = h->dx, dt = h->dt;
+    a.N = h->N;
+    a.n_act = h->n_act;
+    a.F = h->d_F;
+    a.dt = dt;
+    a.dx = dx;
+    a.dx2 = dx * dx;          // python: self.dx**2
+    a.dx4 = std::pow(dx, 4.0);  // python: self.dx**4
+    // merged linear stencil  -(u_xxxx + u_xx):  c_k = -(D4_k/dx^4 + D2_k/dx^2)
+    const double d2[5] = {-49.0 / 18, 3.0 / 2, -3.0 / 20, 1.0 / 90, 0.0};
+    const double d4[5] = {91.0 / 8, -122.0 / 15, 169.0 / 60, -2.0 / 5, 7.0 / 240};
+    for (int k = 0; k < 5; ++k) a.c_lin[k] = -(d4[k] / a.dx4 + d2[k] / a.dx2);
+    a.mh_inv_dx = -0.5 / dx;
+    a.hdt = dt / 2.0;
+    a.dt6 = dt / 6.0;
+    a.dt3 = dt / 3.0;
+}
+
+// Choose (variant, G, P, block, grid) for n_rows envs.
+int choose_layout(const ks_handle* h, int n_rows, ks::Layout& lay) {
+    const int N = h->N;
+    int variant = h->variant;
+    if (variant == KS_VARIANT_AUTO) {
+        // Prefer 16-lane groups (cheapest halo: one DPP row rotation per halo value, most points
+        // per lane) when that still yields >= 1 wave per SIMD (4 * CUs waves); otherwise spread
+        // each env over a full wavefront to expose more waves.
+        const long waves16 = ((long)n_rows * 16 + 63) / 64;
+        const bool ok16 = ks::layout_supported(KS_VARIANT_ROW16_DPP, N);
+        const bool ok64 = ks::layout_supported(KS_VARIANT_WAVE64_DPP, N);
+        if (ok16 && (waves16 >= 4L * h->num_cus || !ok64))
+            variant = KS_VARIANT_ROW16_DPP;
+        else if (ok64)
+            variant = KS_VARIANT_WAVE64_DPP;
+        else if (ks::layout_supported(KS_VARIANT_HALF32_BPERM, N))
+            variant = KS_VARIANT_HALF32_BPERM;
+        else
+            variant = KS_VARIANT_LDS;
+    }
+    if (!ks::layout_supported(variant, N))
+        return fail(KS_ERR_UNSUPPORTED, "kernel variant %d has no instantiation for N=%d", variant, N);
+    lay.variant = variant;
+    lay.lds_bytes = 0;
+    if (variant == KS_VARIANT_LDS) {
+        int block = h->block_threads ? h->block_threads : (N <= 64 ? 64 : (N <= 128 ? 128 : 256));
+        lay.G = 0;
+        lay.P = 0;
+        lay.block = block;
+        lay.grid = n_rows;
+        lay.lds_bytes = sizeof(double) * (5 * (size_t)N + block / 64);
+        return KS_OK;
+    }
+    lay.G = (variant == KS_VARIANT_ROW16_DPP || variant == KS_VARIANT_ROW16_BPERM) ? 16
+            : (variant == KS_VARIANT_HALF32_BPERM)                                  ? 32
+                                                                                    : 64;
+    lay.P = N / lay.G;
+    const int epw = 64 / lay.G;
+    const long waves = ((long)n_rows + epw - 1) / epw;
+    int block = h->block_threads;
+    if (!block) {
+        // one wave per SIMD per workgroup when there are enough waves to give every CU a full
+        // workgroup; single-wave workgroups otherwise so the dispatcher can spread them
+        block = (waves >= 4L * h->num_cus) ? 256 : 64;
+    }
+    const int wpb = block / 64;
+    lay.block = block;
+    lay.grid = (int)((waves + wpb - 1) / wpb);
+    return KS_OK;
+}
+
+int do_step(ks_handle* h, const float* d_phi, const float* d_actions, const int* d_env_ids, int n_rows,
+            long n_substeps, float* d_obs, double* d_ssq, int* d_status) {
+    if (n_substeps < 0) return fail(KS_ERR_INVALID, "n_substeps < 0");
+    if (d_phi && d_actions) return fail(KS_ERR_INVALID, "give phi or actions, not both");
+    if (d_actions && (!h->d_F || h->n_act <= 0))
+        return fail(KS_ERR_INVALID, "ks_step_actions needs ks_set_forcing first");
+    const int rows = d_env_ids ? n_rows : h->E;
+    if (rows < 0 || rows > h->E) return fail(KS_ERR_INVALID, "n_rows out of range");
+    ks::Layout lay;
+    int rc = choose_layout(h, rows, lay);
+    if (rc != KS_OK) return rc;
+    ks::StepArgs a;
+    fill_args(h, a);
+    a.u = h->d_u;
+    a.phi = d_phi;
+    a.actions = d_actions;
+    a.env_ids = d_env_ids;
+    a.obs = d_obs;
+    a.ssq_sum = d_ssq;
+    a.status = d_status;
+    a.n_rows = rows;
+    a.n_substeps = n_substeps;
+    KS_HIP(ks::launch_step(lay, h->mode, a, h->stream));
+    return KS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* ks_last_error(void) { return g_err; }
+const char* ks_version(void) { return "kspde 0.1 (gfx950)"; }
+
+int ks_create(int device, int num_envs, int N, double L, double dt, ks_handle** out) {
+    if (!out) return fail(KS_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (num_envs <= 0 || N < 9 || !(L > 0) || !(dt > 0))
+        return fail(KS_ERR_INVALID, "need num_envs > 0, N >= 9, L > 0, dt > 0 (got %d, %d, %g, %g)", num_envs, N,
+                    L, dt);
+    if ((size_t)num_envs * (size_t)N > (size_t)1 << 31)
+        return fail(KS_ERR_INVALID, "num_envs * N too large");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return fail(KS_ERR_NO_DEVICE, "no HIP device available (libkspde has no CPU path)");
+    if (device < 0 || device >= count)
+        return fail(KS_ERR_NO_DEVICE, "device %d out of range (%d visible)", device, count);
+    DeviceGuard g(device);
+    if (!g.ok) return fail(KS_ERR_HIP, "hipSetDevice(%d) failed", device);
+    ks_handle* h = new (std::nothrow) ks_handle();
+    if (!h) return fail(KS_ERR_INVALID, "out of host memory");
+    h->device = device;
+    h->E = num_envs;
+    h->N = N;
+    h->L = L;
+    h->dt = dt;
+    h->dx = L / N;  // kuramoto.py:55
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+        h->num_cus = prop.multiProcessorCount;
+    const size_t en = (size_t)num_envs * N;
+#define KS_ALLOC(ptr, bytes)                                                        \
+    do {                                                                            \
+        hipError_t e_ = hipMalloc((void**)&(ptr), (bytes));                         \
+        if (e_ != hipSuccess) {                                                     \
+            ks_destroy(h);                                                          \
+            return fail(KS_ERR_HIP, "hipMalloc(%zu) failed: %s", (size_t)(bytes),   \
+                        hipGetErrorString(e_));                                     \
+        }                                                                           \
+    } while (0)
+    KS_ALLOC(h->d_u, en * sizeof(double));
+    KS_ALLOC(h->d_phi, en * sizeof(float));
+    KS_ALLOC(h->d_obs, en * sizeof(float));
+    KS_ALLOC(h->d_rows, en * sizeof(double));
+    KS_ALLOC(h->d_ssq, num_envs * sizeof(double));
+    KS_ALLOC(h->d_status, num_envs * sizeof(int));
+    KS_ALLOC(h->d_ids, num_envs * sizeof(int));
+    KS_ALLOC(h->d_flag, sizeof(unsigned));
+#undef KS_ALLOC
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+        ks_destroy(h);
+        return fail(KS_ERR_HIP, "hipStreamCreate failed");
+    }
+    h->own_stream = true;
+    if (hipMemsetAsync(h->d_u, 0, en * sizeof(double), h->stream) != hipSuccess ||
+        hipStreamSynchronize(h->stream) != hipSuccess) {
+        ks_destroy(h);
+        return fail(KS_ERR_HIP, "initial memset failed");
+    }
+    *out = h;
+    return KS_OK;
+}
+
+int ks_destroy(ks_handle* h) {
+    if (!h) return KS_OK;
+    DeviceGuard g(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    void* bufs[] = {h->d_u, h->d_phi, h->d_act, h->d_F, h->d_obs, h->d_ssq, h->d_status, h->d_ids, h->d_rows,
+                    h->d_flag};
+    for (void* b : bufs)
+        if (b) (void)hipFree(b);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return KS_OK;
+}
+
+int ks_set_stream(ks_handle* h, void* hip_stream) {
+    if (!h) return fail(KS_ERR_INVALID, "NULL handle");
+    DeviceGuard g(h->device);
+    if (h->stream) KS_HIP(hipStreamSynchronize(h->stream));
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    h->stream = (hipStream_t)hip_stream;
+    h->own_stream = false;
+    return KS_OK;
+}
+
+int ks_set_mode(ks_handle* h, int mode) {
+    if (!h) return fail(KS_ERR_INVALID, "NULL handle");
+    if (mode != KS_MODE_FAST && mode != KS_MODE_EXACT) return fail(KS_ERR_INVALID, "unknown mode %d", mode);
+    h->mode = mode;
+    return KS_OK;
+}
+
+int ks_set_variant(ks_handle* h, int variant) {
+    if (!h) return fail(KS_ERR_INVALID, "NULL handle");
+    if (variant != KS_VARIANT_AUTO && !ks::layout_supported(variant, h->N))
+        return fail(KS_ERR_UNSUPPORTED, "variant %d not available for N=%d", variant, h->N);
+    h->variant = variant;
+    return KS_OK;
+}
+
+int ks_set_block_size(ks_handle* h, int threads) {
+    if (!h) return fail(KS_ERR_INVALID, "NULL handle");
+    if (threads != 0 && threads != 64 && threads != 128 && threads != 256)
+        return fail(KS_ERR_INVALID, "block size must be 0, 64, 128 or 256");
+    h->block_threads = threads;
+    return KS_OK;
+}
+
+int ks_get_layout(ks_handle* h, int* variant, int* lanes_per_env, int* points_per_lane, int* block_threads,
+                  int* grid_blocks) {
+    if (!h) return fail(KS_ERR_INVALID, "NULL handle");
+    ks::Layout lay;
+    int rc = choose_layout(h, h->E, lay);
+    if (rc != KS_OK) return rc;
+    if (variant) *variant = lay.variant;
+    if (lanes_per_env) *lanes_per_env = lay.G;
+    if (points_per_lane) *points_per_lane = lay.P;
+    if (block_threads) *block_threads = lay.block;
+    if (grid_blocks) *grid_blocks = lay.grid;
+    return KS_OK;
+}
+
+int ks_set_forcing(ks_handle* h, const float* F_host, int n_act) {
+    if (!h || !F_host) return fail(KS_ERR_INVALID, "NULL argument");
+    if (n_act <= 0 || n_act > 64) return fail(KS_ERR_INVALID, "n_act out of range");
+    DeviceGuard g(h->device);
+    KS_HIP(hipStreamSynchronize(h->stream));
+    if (h->d_F) (void)hipFree(h->d_F);
+    if (h->d_act) (void)hipFree(h->d_act);
+    h->d_F = nullptr;
+    h->d_act = nullptr;
+    KS_HIP(hipMalloc((void**)&h->d_F, sizeof(float) * (size_t)n_act * h->N));
+    KS_HIP(hipMalloc((void**)&h->d_act, sizeof(float) * (size_t)n_act * h->E));
+    KS_HIP(hipMemcpyAsync(h->d_F, F_host, sizeof(float) * (size_t)n_act * h->N, hipMemcpyHostToDevice, h->stream));
+    KS_HIP(hipStreamSynchronize(h->stream));
+    h->n_act = n_act;
+    return KS_OK;
+}
+
+int ks_set_state(ks_handle* h, const double* u_host) {
+    if (!h || !u_host) return fail(KS_ERR_INVALID, "NULL argument");
+    DeviceGuard g(h->device);
+    KS_HIP(hipMemcpyAsync(h->d_u, u_host, sizeof(double) * (size_t)h->E * h->N, hipMemcpyHostToDevice, h->stream));
+    KS_HIP(hipStreamSynchronize(h->stream));
+    return KS_OK;
+}
+
+int ks_get_state(ks_handle* h, double* u_host) {
+    if (!h || !u_host) return fail(KS_ERR_INVALID, "NULL argument");
+    DeviceGuard g(h->device);
+    KS_HIP(hipMemcpyAsync(u_host, h->d_u, sizeof(double) * (size_t)h->E * h->N, hipMemcpyDeviceToHost, h->stream));
+    KS_HIP(hipStreamSynchronize(h->stream));
+    return KS_OK;
+}
+
+int ks_set_state_rows(ks_handle* h, const int* env_ids_host, int n, const double* u_host) {
+    if (!h || (n > 0 && (!env_ids_host || !u_host))) return fail(KS_ERR_INVALID, "NULL argument");
+    if (n < 0 || n > h->E) return fail(KS_ERR_INVALID, "n out of range");
+    for (int i = 0; i < n; ++i)
+        if (env_ids_host[i] < 0 || env_ids_host[i] >= h->E)
+            return fail(KS_ERR_INVALID, "env id %d out of range", env_ids_host[i]);
+    DeviceGuard g(h->device);
+    const size_t row = sizeof(double) * (size_t)h->N;
+    for (int i = 0; i < n; ++i)
+        KS_HIP(hipMemcpyAsync(h->d_u + (size_t)env_ids_host[i] * h->N, u_host + (size_t)i * h->N, row,
+                              hipMemcpyHostToDevice, h->stream));
+    KS_HIP(hipStreamSynchronize(h->stream));
+    return KS_OK;
+}
+
+int ks_state_device_ptr(ks_handle* h, double** d_u) {
+    if (!h || !d_u) return fail(KS_ERR_INVALID, "NULL argument");
+    *d_u = h->d_u;
+    return KS_OK;
+}
+
+static int step_common(ks_handle* h, const float* d_phi, const float* d_act, const int* d_ids, int n_rows,
+                       long n_substeps, float* obs_f32, double* ssq_sum, int* status, bool compact_rows) {
+    int rc = do_step(h, d_phi, d_act, d_ids, n_rows, n_substeps, obs_f32 ? h->d_obs : nullptr,
+                     ssq_sum ? h->d_ssq : nullptr, status ? h->d_status : nullptr);
+    if (rc != KS_OK) return rc;
+    const int rows = d_ids ? n_rows : h->E;
+    (void)compact_rows;
+    if (!d_ids) {
+        if (obs_f32)
+            KS_HIP(hipMemcpyAsync(obs_f32, h->d_obs, sizeof(float) * (size_t)rows * h->N, hipMemcpyDeviceToHost,
+                                  h->stream));
+        if (ssq_sum)
+            KS_HIP(hipMemcpyAsync(ssq_sum, h->d_ssq, sizeof(double) * rows, hipMemcpyDeviceToHost, h->stream));
+        if (status)
+            KS_HIP(hipMemcpyAsync(status, h->d_status, sizeof(int) * rows, hipMemcpyDeviceToHost, h->stream));
+    }
+    KS_HIP(hipStreamSynchronize(h->stream));
+    return KS_OK;
+}
+
+int ks_step(ks_handle* h, const float* phi_host, long n_substeps, float* obs_f32, double* ssq_sum, int* status) {
+    if (!h) return fail(KS_ERR_INVALID, "NULL handle");
+    DeviceGuard g(h->device);
+    const float* d_phi = nullptr;
+    if (phi_host) {
+        KS_HIP(hipMemcpyAsync(h->d_phi, phi_host, sizeof(float) * (size_t)h->E * h->N, hipMemcpyHostToDevice,
+                              h->stream));
+        d_phi = h->d_phi;
+    }
+    return step_common(h, d_phi, nullptr, nullptr, 0, n_substeps, obs_f32, ssq_sum, status, false);
+}
+
+int ks_step_actions(ks_handle* h, const float* actions_host, long n_substeps, float* obs_f32, double* ssq_sum,
+                    int* status) {
+    if (!h || !actions_host) return fail(KS_ERR_INVALID, "NULL argument");
+    if (!h->d_F) return fail(KS_ERR_INVALID, "ks_step_actions needs ks_set_forcing first");
+    DeviceGuard g(h->device);
+    KS_HIP(hipMemcpyAsync(h->d_act, actions_host, sizeof(float) * (size_t)h->E * h->n_act, hipMemcpyHostToDevice,
+                          h->stream));
+    return step_common(h, nullptr, h->d_act, nullptr, 0, n_substeps, obs_f32, ssq_sum, status, false);
+}
+
+int ks_step_rows(ks_handle* h, const int* env_ids_host, int n, long n_substeps, float* obs_f32, double* ssq_sum,
+                 int* status) {
+    if (!h || (n > 0 && !env_ids_host)) return fail(KS_ERR_INVALID, "NULL argument");
+    if (n < 0 || n > h->E) return fail(KS_ERR_INVALID, "n out of range");
+    if (n == 0) return KS_OK;
+    for (int i = 0; i < n; ++i)
+        if (env_ids_host[i] < 0 || env_ids_host[i] >= h->E)
+            return fail(KS_ERR_INVALID, "env id %d out of range", env_ids_host[i]);
+    DeviceGuard g(h->device);
+    KS_HIP(hipMemcpyAsync(h->d_ids, env_ids_host, sizeof(int) * n, hipMemcpyHostToDevice, h->stream));
+    int rc = step_common(h, nullptr, nullptr, h->d_ids, n, n_substeps, obs_f32, ssq_sum, status, true);
+    if (rc != KS_OK) return rc;
+    // outputs are indexed by env id on the device; hand them back compacted in list order
+    const size_t row = sizeof(float) * (size_t)h->N;
+    for (int i = 0; i < n; ++i) {
+        const int e = env_ids_host[i];
+        if (obs_f32)
+            KS_HIP(hipMemcpyAsync(obs_f32 + (size_t)i * h->N, h->d_obs + (size_t)e * h->N, row,
+                                  hipMemcpyDeviceToHost, h->stream));
+        if (ssq_sum)
+            KS_HIP(hipMemcpyAsync(ssq_sum + i, h->d_ssq + e, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        if (status)
+            KS_HIP(hipMemcpyAsync(status + i, h->d_status + e, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    }
+    KS_HIP(hipStreamSynchronize(h->stream));
+    return KS_OK;
+}
+
+int ks_step_device(ks_handle* h, const float* d_phi, const float* d_actions, const int* d_env_ids, int n_rows,
+                   long n_substeps, float* d_obs_f32, double* d_ssq_sum, int* d_status) {
+    if (!h) return fail(KS_ERR_INVALID, "NULL handle");
+    DeviceGuard g(h->device);
+    return do_step(h, d_phi, d_actions, d_env_ids, n_rows, n_substeps, d_obs_f32, d_ssq_sum, d_status);
+}
+
+int ks_sync(ks_handle* h) {
+    if (!h) return fail(KS_ERR_INVALID, "NULL handle");
+    DeviceGuard g(h->device);
+    KS_HIP(hipStreamSynchronize(h->stream));
+    return KS_OK;
+}
+
+int ks_rhs(ks_handle* h, const double* u_host, const float* phi_host, int n_rows, double* rhs, double* ux,
+           double* uxx, double* uxxxx) {
+    if (!h || !u_host || !phi_host || !rhs) return fail(KS_ERR_INVALID, "NULL argument");
+    if (n_rows <= 0) return fail(KS_ERR_INVALID, "n_rows <= 0");
+    DeviceGuard g(h->device);
+    const size_t n = (size_t)n_rows * h->N;
+    double *d_u = nullptr, *d_out = nullptr;
+    float* d_phi = nullptr;
+    KS_HIP(hipMalloc((void**)&d_u, n * sizeof(double)));
+    hipError_t e1 = hipMalloc((void**)&d_out, 4 * n * sizeof(double));
+    hipError_t e2 = hipMalloc((void**)&d_phi, n * sizeof(float));
+    int rc = KS_OK;
+    if (e1 != hipSuccess || e2 != hipSuccess) {
+        rc = fail(KS_ERR_HIP, "hipMalloc failed in ks_rhs");
+    } else {
+        hipError_t e = hipMemcpyAsync(d_u, u_host, n * sizeof(double), hipMemcpyHostToDevice, h->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_phi, phi_host, n * sizeof(float), hipMemcpyHostToDevice, h->stream);
+        const double dx = h->dx;
+        if (e == hipSuccess)
+            e = ks::launch_rhs(d_u, d_phi, n_rows, h->N, dx, dx * dx, std::pow(dx, 4.0), d_out, d_out + n,
+                               d_out + 2 * n, d_out + 3 * n, h->stream);
+        double* outs[4] = {rhs, ux, uxx, uxxxx};
+        for (int k = 0; k < 4 && e == hipSuccess; ++k)
+            if (outs[k]) e = hipMemcpyAsync(outs[k], d_out + k * n, n * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) rc = fail(KS_ERR_HIP, "ks_rhs: %s", hipGetErrorString(e));
+    }
+    if (d_u) (void)hipFree(d_u);
+    if (d_out) (void)hipFree(d_out);
+    if (d_phi) (void)hipFree(d_phi);
+    return rc;
+}
+
+int ks_selftest(ks_handle* h, unsigned* failed_mask) {
+    if (!h) return fail(KS_ERR_INVALID, "NULL handle");
+    DeviceGuard g(h->device);
+    unsigned m = 0;
+    KS_HIP(hipMemsetAsync(h->d_flag, 0, sizeof(unsigned), h->stream));
+    KS_HIP(ks::launch_selftest(h->d_flag, h->stream));
+    KS_HIP(hipMemcpyAsync(&m, h->d_flag, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+    KS_HIP(hipStreamSynchronize(h->stream));
+    if (failed_mask) *failed_mask = m;
+    if (m) return fail(KS_ERR_SELFTEST, "cross-lane self test failed, variant mask 0x%x", m);
+    return KS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,30 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "model-based-pde-control_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+# (tag -> (L, N)) of the configurations the golden fixtures were generated for
+KS_CONFIGS = {"n64": (22.0, 64), "n256": (88.0, 256), "n48": (16.5, 48), "n128": (44.0, 128)}
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def ks_golden():
+    return np.load(os.path.join(GOLDEN, "ks_golden.npz"))
+
+
+@pytest.fixture(scope="session")
+def sur_golden():
+    return np.load(os.path.join(GOLDEN, "surrogate_golden.npz"))
