@@ -40,19 +40,23 @@ static const double TAB_D2[7] = {1.0 / 90, -3.0 / 20, 3.0 / 2, -49.0 / 18, 3.0 /
 static const double TAB_D4[9] = {7.0 / 240, -2.0 / 5,   169.0 / 60, -122.0 / 15, 91.0 / 8,
                                  -122.0 / 15, 169.0 / 60, -2.0 / 5,  7.0 / 240};
 
-static inline int wrap(int i, int n) {
-    i %= n;
-    return i < 0 ? i + n : i;
+/* All stencil loops read from a periodically padded copy pad[0 .. n+2H-1] with
+ * pad[H + i] = in[i mod n], so that the inner loops are plain strided reads. */
+static void pad_periodic(const double *in, int n, double *pad) {
+    for (int i = 0; i < H; ++i) pad[i] = in[((n - H + i) % n + n) % n];
+    memcpy(pad + H, in, sizeof(double) * (size_t)n);
+    for (int i = 0; i < H; ++i) pad[H + n + i] = in[i % n];
 }
 
-/* scipy convolve1d(mode="wrap") for an odd-length table; general (non-symmetric) path */
+/* scipy convolve1d(mode="wrap") for an odd-length table; general (non-symmetric) path.
+ * in = padded + H (so in[-H .. n+H-1] are valid). */
 static void conv_general(const double *in, int n, const double *tab, int len, double *out) {
     int h = len / 2;
     double w[9]; /* flipped = correlation weights, w[j+h] multiplies in[i+j] */
     for (int j = 0; j < len; ++j) w[j] = tab[len - 1 - j];
     for (int i = 0; i < n; ++i) {
-        double t = in[wrap(i + h, n)] * w[2 * h];
-        for (int j = -h; j < h; ++j) t += in[wrap(i + j, n)] * w[j + h];
+        double t = in[i + h] * w[2 * h];
+        for (int j = -h; j < h; ++j) t += in[i + j] * w[j + h];
         out[i] = t;
     }
 }
@@ -62,20 +66,22 @@ static void conv_symmetric(const double *in, int n, const double *tab, int len, 
     int h = len / 2;
     for (int i = 0; i < n; ++i) {
         double t = in[i] * tab[h];
-        for (int j = -h; j < 0; ++j) t += (in[wrap(i + j, n)] + in[wrap(i - j, n)]) * tab[j + h];
+        for (int j = -h; j < 0; ++j) t += (in[i + j] + in[i - j]) * tab[j + h];
         out[i] = t;
     }
 }
 
-/* kuramoto.py:118-129 for one env.  Any of ux/uxx/uxxxx may be NULL. */
+/* kuramoto.py:118-129 for one env.  Any of ux/uxx/uxxxx may be NULL.  scratch: RHS_SCRATCH(n) doubles */
 static void rhs_one(const double *u, const float *phi, int n, double dx, double *rhs, double *ux,
-                    double *uxx, double *uxxxx, double *scratch /* 6*n */) {
-    double *q = scratch, *fwd = q + n, *bwd = fwd + n, *d1 = bwd + n, *d2 = d1 + n, *d4 = d2 + n;
-    for (int i = 0; i < n; ++i) q[i] = u[i] * u[i];
-    conv_general(q, n, TAB_FWD, 9, fwd);
-    conv_general(q, n, TAB_BWD, 9, bwd);
-    conv_symmetric(u, n, TAB_D2, 7, d2);
-    conv_symmetric(u, n, TAB_D4, 9, d4);
+                    double *uxx, double *uxxxx, double *scratch) {
+    double *fwd = scratch, *bwd = fwd + n, *d1 = bwd + n, *d2 = d1 + n, *d4 = d2 + n;
+    double *up = d4 + n, *qp = up + n + 2 * H;
+    pad_periodic(u, n, up);
+    for (int i = 0; i < n + 2 * H; ++i) qp[i] = up[i] * up[i];
+    conv_general(qp + H, n, TAB_FWD, 9, fwd);
+    conv_general(qp + H, n, TAB_BWD, 9, bwd);
+    conv_symmetric(up + H, n, TAB_D2, 7, d2);
+    conv_symmetric(up + H, n, TAB_D4, 9, d4);
     double dx2 = dx * dx, dx4 = pow(dx, 4.0); /* python: self.dx**2, self.dx**4 */
     for (int i = 0; i < n; ++i) {
         double f = fwd[i] / dx, b = bwd[i] / dx;
@@ -90,10 +96,12 @@ static void rhs_one(const double *u, const float *phi, int n, double dx, double 
     if (uxxxx) memcpy(uxxxx, d4, sizeof(double) * n);
 }
 
+#define RHS_SCRATCH(n) (7 * (size_t)(n) + 4 * H)
+
 /* Batched rhs test hook: u [E,N] f64, phi [E,N] f32 -> rhs, ux, uxx, uxxxx [E,N] f64 */
 int ks_oracle_rhs(const double *u, const float *phi, int E, int N, double dx, double *rhs,
                   double *ux, double *uxx, double *uxxxx) {
-    double *scratch = (double *)malloc(sizeof(double) * 6 * (size_t)N);
+    double *scratch = (double *)malloc(sizeof(double) * RHS_SCRATCH(N));
     if (!scratch) return -1;
     for (int e = 0; e < E; ++e) {
         size_t o = (size_t)e * N;
@@ -108,7 +116,7 @@ int ks_oracle_rhs(const double *u, const float *phi, int E, int N, double dx, do
  * reward_sum receives sum over sub-steps of  -(1/N) * norm(u)**2  (NOT yet / cfg_steps).
  * ssq_sum (optional) receives the raw sum over sub-steps of sum_i u_i^2. */
 static void step_one(double *u, const float *phi, int n, double dx, double dt, long n_substeps,
-                     double *reward_sum, double *ssq_sum, double *work /* 11*n */) {
+                     double *reward_sum, double *ssq_sum, double *work /* 5*n + RHS_SCRATCH */) {
     double *k1 = work, *k2 = k1 + n, *k3 = k2 + n, *k4 = k3 + n, *us = k4 + n, *scratch = us + n;
     double reward = 0.0, ssq_tot = 0.0;
     for (long s = 0; s < n_substeps; ++s) {
@@ -138,7 +146,7 @@ int ks_oracle_step(double *u, const float *phi, int E, int N, double dx, double 
     int fail = 0;
 #pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1) reduction(| : fail)
     for (int e = 0; e < E; ++e) {
-        double *work = (double *)malloc(sizeof(double) * 11 * (size_t)N);
+        double *work = (double *)malloc(sizeof(double) * (5 * (size_t)N + RHS_SCRATCH(N)));
         if (!work) {
             fail |= 1;
             continue;

@@ -135,3 +135,39 @@ def step_numpy(u, phi, dx, dt, n_substeps):
         k4 = rhs_numpy(u + dt * k3, phi, dx)[0]
         u = u + dt * (k1 + 2.0 * k2 + 2.0 * k3 + k4) / 6.0
     return u, reward
+
+
+# --------------------------------------------------------------------------- #
+# "Reference-structured" per-env Python baseline (baseline A): one env
+# object per process, a Python loop over sub-steps, 16 scipy.ndimage.convolve1d(mode="wrap")
+# calls and one numpy->torch->numpy reward round trip per sub-step -- the cost structure of
+# pdegym/kuramoto/kuramoto.py:78-129, restated (not copied) for timing only.
+# --------------------------------------------------------------------------- #
+def step_scipy_structured(u, phi, dx, dt, n_substeps):
+    import torch
+    from scipy.ndimage import convolve1d
+    tab_fwd = [-1 / 4, 4 / 3, -3, 4, -25 / 12, 0, 0, 0, 0]
+    tab_bwd = [0, 0, 0, 0, 25 / 12, -4, 3, -4 / 3, 1 / 4]
+    tab_d2 = [1 / 90, -3 / 20, 3 / 2, -49 / 18, 3 / 2, -3 / 20, 1 / 90]
+    tab_d4 = [7 / 240, -2 / 5, 169 / 60, -122 / 15, 91 / 8, -122 / 15, 169 / 60, -2 / 5, 7 / 240]
+    N = u.shape[-1]
+
+    def f(v):
+        q = v ** 2
+        fw = convolve1d(q, weights=tab_fwd, mode="wrap") / dx
+        bw = convolve1d(q, weights=tab_bwd, mode="wrap") / dx
+        ux = (v < 0) * fw + (v >= 0) * bw
+        uxx = convolve1d(v, weights=tab_d2, mode="wrap") / dx ** 2
+        uxxxx = convolve1d(v, weights=tab_d4, mode="wrap") / dx ** 4
+        return -uxxxx - uxx - 0.5 * ux + phi
+
+    u = np.array(u, dtype=np.float64, copy=True)
+    reward = 0.0
+    for _ in range(int(n_substeps)):
+        reward += ((-1.0) * (1 / N) * torch.norm(torch.from_numpy(u)) ** 2).numpy()
+        k1 = f(u)
+        k2 = f(u + dt * k1 / 2.0)
+        k3 = f(u + dt * k2 / 2.0)
+        k4 = f(u + dt * k3)
+        u = u + dt * (k1 + 2.0 * k2 + 2.0 * k3 + k4) / 6.0
+    return u, float(reward)
