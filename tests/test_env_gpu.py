@@ -1,0 +1,91 @@
+"""The gym env / batched vector env on the real HIP stepper (MI355X)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from conftest import KS_CONFIGS
+
+
+@pytest.fixture(scope="module")
+def api():
+    import pdegym  # noqa: F401
+    from pdegym.kuramoto import KuramotoSivashinskyEnv, make_vec
+    return KuramotoSivashinskyEnv, make_vec
+
+
+def test_single_env_step_and_reset_parity(api, ks_golden):
+    Env, _ = api
+    for tag in ("n64", "n256"):
+        L, N = KS_CONFIGS[tag]
+        # exact arithmetic: bit-identical observations
+        env = Env(L=L, N=N, step_mode="exact")
+        env.u = ks_golden[f"{tag}_traj_u0"][0]
+        obs, rew, term, trunc, info = env.step(ks_golden[f"{tag}_actions"][0])
+        np.testing.assert_array_equal(obs[0], ks_golden[f"{tag}_traj_u250"][0])
+        np.testing.assert_allclose(rew, ks_golden[f"{tag}_traj_rew250"][0], rtol=1e-13)
+        assert obs.dtype == np.float64 and info == {"step": 1} and term is False and not trunc
+        # default (fast) arithmetic: inside the 1e-9 per sub-step contract
+        env = Env(L=L, N=N)
+        env.u = ks_golden[f"{tag}_traj_u0"][0]
+        obs, rew, *_ = env.step(ks_golden[f"{tag}_actions"][0])
+        assert np.abs(obs[0] - ks_golden[f"{tag}_traj_u250"][0]).max() < 1e-9
+        np.testing.assert_allclose(rew, ks_golden[f"{tag}_traj_rew250"][0], rtol=1e-10)
+        # seeded reset = reference reset, bit for bit (burn-in runs in exact mode)
+        obs, info = env.reset(seed=int(ks_golden[f"{tag}_reset_seed"]), return_info=True)
+        np.testing.assert_array_equal(obs[0], ks_golden[f"{tag}_reset_u"])
+        assert info == {"step": 0}
+        rhs, (ux, uxx, uxxxx) = env.rhs(ks_golden[f"{tag}_rhs_u"][0], ks_golden[f"{tag}_rhs_phi"][0])
+        np.testing.assert_array_equal(rhs, ks_golden[f"{tag}_rhs"][0])
+        env.close()
+
+
+def test_single_env_overflow_raises(api):
+    Env, _ = api
+    env = Env(L=22.0, N=256)
+    env.u = np.random.RandomState(0).uniform(-0.4, 0.4, 256)
+    with pytest.raises(FloatingPointError):
+        env.step([[0.0, 0.0, 0.0, 0.0]])
+
+
+def test_vec_env_matches_single_envs_and_autoresets(api, ks_golden):
+    Env, make_vec = api
+    E = 6
+    cfg = {"Tmax": 0.5, "cfg_steps": 250}  # 2 steps per episode
+    vec = make_vec(E, config=cfg, step_mode="exact")
+    assert vec.max_episode_steps == 2
+    obs = vec.reset(seed=40)
+    assert obs.shape == (E, 1, 64) and obs.dtype == np.float32
+    singles = [Env(step_mode="exact", **cfg) for _ in range(E)]
+    for i, s in enumerate(singles):
+        o = s.reset(seed=40 + i)
+        np.testing.assert_array_equal(obs[i, 0], o[0].astype(np.float32))
+    # the golden seeded reset, through the batched path
+    vec1 = make_vec(1)
+    np.testing.assert_array_equal(vec1.reset(seed=int(ks_golden["n64_reset_seed"]))[0, 0],
+                                  ks_golden["n64_reset_u"].astype(np.float32))
+    rs = np.random.RandomState(0)
+    a = rs.uniform(-1, 1, (E, 1, 4)).astype(np.float32)
+    o, r, term, trunc, infos = vec.step(a)
+    ref = [s.step(x) for s, x in zip(singles, a)]
+    np.testing.assert_array_equal(o[:, 0], np.stack([x[0][0] for x in ref]).astype(np.float32))
+    np.testing.assert_allclose(r, [x[1] for x in ref], rtol=1e-13)
+    assert not trunc.any() and "final_observation" not in infos
+    o, r, term, trunc, infos = vec.step(a)
+    ref = [s.step(x) for s, x in zip(singles, a)]
+    assert trunc.all() and infos["_final_observation"].all()
+    np.testing.assert_array_equal(np.stack(list(infos["final_observation"]))[:, 0],
+                                  np.stack([x[0][0] for x in ref]).astype(np.float32))
+    np.testing.assert_array_equal(infos["step"], np.full(E, 2))
+    np.testing.assert_array_equal(vec.timestep, np.zeros(E))
+    assert np.isfinite(o).all() and np.abs(o).max() > 0.4  # burnt-in fresh states
+    vec.close()
+
+
+def test_vec_env_large_batch_runs(api):
+    _, make_vec = api
+    vec = make_vec(1024, burn_in=False)
+    vec.reset(seed=0)
+    o, r, term, trunc, infos = vec.step(np.random.RandomState(1).uniform(-1, 1, (1024, 1, 4)).astype(np.float32))
+    assert o.shape == (1024, 1, 64) and np.isfinite(o).all() and (r < 0).all()
+    assert vec.stepper.layout()["variant"] in ("wave64_dpp", "row16_dpp")
