@@ -1,0 +1,68 @@
+"""pytorch_lightning when importable, otherwise the few names the surrogate code touches.
+
+The shim's LightningModule is an ``nn.Module`` whose ``log`` keeps the latest value per name (as a
+tensor, no host sync); ``Trainer`` is a minimal single-device fit loop (manual zero_grad /
+backward / step over a dataloader) so that tests and bench.py can drive ``training_step`` and
+``configure_optimizers`` the way Lightning does.  pytorch-lightning 1.7.2 is the reference's pin
+(poetry.lock:1371) and is absent from the build image.
+"""
+try:  # pragma: no cover - depends on the environment
+    import pytorch_lightning as pl  # type: ignore
+    IS_SHIM = False
+except ImportError:
+    import types
+
+    import torch
+    from torch import nn
+
+    class LightningModule(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.logged = {}
+
+        def log(self, name, value, *args, **kwargs):
+            self.logged[name] = value.detach() if isinstance(value, torch.Tensor) else value
+
+        @property
+        def device(self):
+            p = next(self.parameters(), None)
+            return p.device if p is not None else torch.device("cpu")
+
+    class LightningDataModule:
+        pass
+
+    class Callback:
+        pass
+
+    class Trainer:
+        def __init__(self, max_steps=-1, max_epochs=1, gradient_clip_val=None, **kwargs):
+            self.max_steps, self.max_epochs, self.gradient_clip_val = max_steps, max_epochs, gradient_clip_val
+            self.global_step = 0
+            self.callback_metrics = {}
+
+        def fit(self, module, train_dataloaders=None, datamodule=None):
+            loader = train_dataloaders if train_dataloaders is not None else datamodule.train_dataloader()
+            optimizers, schedulers = module.configure_optimizers()
+            opt = optimizers[0]
+            module.train()
+            for _ in range(self.max_epochs):
+                for bidx, batch in enumerate(loader):
+                    if 0 <= self.max_steps <= self.global_step:
+                        return
+                    opt.zero_grad(set_to_none=True)
+                    out = module.training_step(batch, bidx)
+                    out["loss"].backward()
+                    if self.gradient_clip_val:
+                        nn.utils.clip_grad_norm_(module.parameters(), self.gradient_clip_val)
+                    opt.step()
+                    self.global_step += 1
+                    self.callback_metrics.update(getattr(module, "logged", {}))
+                for s in schedulers:
+                    s["scheduler"].step()
+
+    pl = types.SimpleNamespace(LightningModule=LightningModule, LightningDataModule=LightningDataModule,
+                               Callback=Callback, Trainer=Trainer,
+                               callbacks=types.SimpleNamespace(Callback=Callback))
+    IS_SHIM = True
+
+__all__ = ["pl", "IS_SHIM"]

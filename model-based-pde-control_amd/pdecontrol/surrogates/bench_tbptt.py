@@ -1,0 +1,100 @@
+"""Surrogate TBPTT seqs/s: KSAutoRegConvolutionalLSTM, B=64, T=20, tau=5, tbtt=10,
+N=64, Adam lr 1e-3, undscaling = Normalize(mean 0.01, var 0.5); synthetic U(-1,1) inputs."""
+import time
+
+import torch
+
+from pdecontrol.architectures import KSAutoRegConvolutionalLSTM
+from pdecontrol.surrogates.training import PDETrainingModule
+from pdegym.common.transforms import BatchTransform, Normalize
+
+
+def build_module(device, seed=0):
+    torch.manual_seed(seed)
+    norm = Normalize(aggregate=True, batched=True)
+    norm.mean, norm.var, norm.count = torch.full((1, 1, 1), 0.01), torch.full((1, 1, 1), 0.5), 100
+    undscaling = BatchTransform(norm)
+    factory = KSAutoRegConvolutionalLSTM()
+    surrogate = factory.surrogate(delta=0.25, dscaling=undscaling.Inverse, tau=5, **factory.model())
+    module = PDETrainingModule(surrogate=surrogate, loss=torch.nn.MSELoss(reduction="none"), tstep=0.25, delta=0.25,
+                               undscaling=undscaling, tau=5, tbtt=10)
+    return module.to(device)
+
+
+def synthetic_batch(B=64, T=20, N=64, device="cpu"):
+    g = torch.Generator().manual_seed(1)
+    s = torch.rand(B, T, 1, N, generator=g) * 2 - 1
+    a = torch.rand(B, T, 1, N, generator=g) * 2 - 1
+    return s.to(device), a.to(device)
+
+
+def time_eager(module, batch, steps, warmup):
+    opt = module.configure_optimizers()[0][0]
+    dev = batch[0].device
+
+    def one():
+        opt.zero_grad(set_to_none=True)
+        out = module.training_step(batch, 0)
+        out["loss"].backward()
+        opt.step()
+        return out
+    for _ in range(warmup):
+        one()
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = one()
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)
+    return (time.perf_counter() - t0) / steps, float(out["loss"].detach())
+
+
+def first_loss(device, B):
+    """Loss of the very first training_step of a freshly seeded module (no update applied)."""
+    module = build_module(device)
+    with torch.no_grad():
+        return float(module.training_step(synthetic_batch(B=B, device=device), 0)["loss"])
+
+
+def run(device, steps=50, warmup=5, B=64, cpu_steps=3):
+    from pdecontrol.surrogates.graph_step import GraphedTBPTTStep
+    batch = synthetic_batch(B=B, device=device)
+    res = {"unit": "seqs/s", "config": {"factory": "KSAutoRegConvolutionalLSTM", "B": B, "T": 20, "tau": 5,
+                                        "tbtt": 10, "N": 64, "dtype": "f32", "optimizer": "Adam lr 1e-3",
+                                        "step": "training_step + backward + Adam"}}
+    module = build_module(device)
+    dt, _ = time_eager(module, batch, steps=10, warmup=2)
+    res["eager"] = {"value": B / dt, "ms_per_step": dt * 1e3}
+
+    module = build_module(device)
+    graphed = GraphedTBPTTStep(module, tuple(batch[0].shape))
+    graphed.step(*batch)
+    for _ in range(warmup):
+        graphed.step()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        graphed.step()
+    torch.cuda.synchronize(device)
+    dt = (time.perf_counter() - t0) / steps
+    res["hip_graph"] = {"value": B / dt, "ms_per_step": dt * 1e3, "steps": steps,
+                        "loss_after_training": float(graphed.result["loss"].detach())}
+    res["value"] = res["hip_graph"]["value"]
+
+    # parity of the measured configuration: first-step loss GPU vs CPU (contract: 1e-5 relative)
+    loss_gpu, loss_cpu = first_loss(device, B), first_loss("cpu", B)
+    res["first_loss"] = {"gpu": loss_gpu, "cpu": loss_cpu, "rel_diff": abs(loss_gpu - loss_cpu) / abs(loss_cpu)}
+
+    # CPU baseline: the same nn.Module tree / training_step / Adam on torch CPU kernels (what the
+    # reference runs), at 1 thread (the reference's regime for these tiny ops) and at 16 threads
+    best = None
+    for nthreads in (1, min(16, torch.get_num_threads())):
+        torch.set_num_threads(nthreads)
+        dt_cpu, _ = time_eager(build_module("cpu"), synthetic_batch(B=B), steps=cpu_steps, warmup=1)
+        if best is None or dt_cpu < best[0]:
+            best = (dt_cpu, nthreads)
+    res["cpu_baseline"] = {"value": B / best[0], "unit": "seqs/s", "cores": best[1], "kind": "port",
+                           "sample": f"same nn.Module tree + training_step + Adam on torch CPU kernels, "
+                                     f"{cpu_steps} steps, best of 1 / 16 threads"}
+    return res

@@ -1,0 +1,169 @@
+"""Truncated-BPTT training module of the surrogate.
+
+API mirror of the reference's ``pdecontrol/surrogates/training.py`` (``PDETrainingModule`` :14-62,
+``training_step`` :64-130, ``validation_step`` :132-174, ``test_step`` :176-271,
+``configure_optimizers`` :273-278): same constructor, same returned-dict keys, same logged metric
+names ("Train Loss", "Val. Loss", ...).
+
+What is different under the hood: logged values stay tensors (no ``.item()`` host sync inside
+the step), time grids are Python-side, and ``fused_step`` offers the whole
+forward + backward + Adam update as ONE replayable HIP graph for fixed batch shapes.
+"""
+from functools import reduce
+from typing import Callable
+
+import numpy as np
+import torch
+
+from pdecontrol._compat.lightning import pl
+from pdecontrol.mbrl.types import ModelRollout
+from pdecontrol.surrogates.surrogate import AutoRegPDESurrogate, LatentAutoRegPDESurrogate, PDESurrogate
+from pdegym.common.transforms import BatchTransform, Identity, SampleTransform
+
+
+class PDETrainingModule(pl.LightningModule):
+    def __init__(self, surrogate: PDESurrogate, loss: Callable, tstep: float, delta: float, env=None,
+                 stransf: SampleTransform = None, undscaling: BatchTransform = None, tau: int = 5, tbtt: int = 10,
+                 lr: float = 1e-03, lr_gamma: float = 1.0, step_size: int = 25, **kwargs):
+        super().__init__()
+        self.surrogate, self.loss, self.tstep, self.delta, self.env = surrogate, loss, tstep, delta, env
+        self.stransf = SampleTransform() if stransf is None else stransf
+        self.undscaling = BatchTransform(Identity()) if undscaling is None else undscaling
+        self.tau, self.tbtt, self.lr, self.lr_gamma, self.step_size = tau, tbtt, lr, lr_gamma, step_size
+        if isinstance(surrogate, AutoRegPDESurrogate):
+            self.training_mode = "delta"
+        elif isinstance(surrogate, LatentAutoRegPDESurrogate):
+            self.training_mode = "decoded"
+        else:
+            raise ValueError
+        assert self.tbtt > self.tau, "Chunk size of TBTT must be larger than warm-up length."
+
+    # -- helpers -----------------------------------------------------------------------------
+    def _grid(self, n):
+        """times / targets of an n-action chunk: k*tstep and (k+1)*tstep (CPU tensors)."""
+        k = torch.arange(n)
+        return self.tstep * k, self.tstep * (k + 1)
+
+    def _full_rollout(self, states, actions) -> ModelRollout:
+        times, targets = self._grid(actions.size(1))
+        return self.surrogate.rollout(states=states[:, :self.tau], actions=actions, times=times, targets=targets,
+                                      hidden=None)
+
+    # -- training: truncated back-propagation through time ------------------------------------
+    def tbptt_forward(self, states, actions):
+        """Chunks of ``tbtt`` steps; chunk 0 warms up on the first ``tau`` true states, later chunks
+        start from the previous chunk's last prediction with gradients cut (state and hidden)."""
+        rollouts = []
+        seed_states, hidden = None, None
+        if isinstance(self.surrogate, AutoRegPDESurrogate):
+            self.surrogate.reencode_predictions = False  # inlatents are never read by the loss
+        for c, achunk in enumerate(torch.split(actions, self.tbtt, dim=1)):
+            if c == 0:
+                seed_states = states[:, :self.tbtt][:, :self.tau]
+            times, targets = self._grid(achunk.size(1))
+            out = self.surrogate.rollout(states=seed_states, actions=achunk, times=times, targets=targets,
+                                         hidden=hidden)
+            rollouts.append(out)
+            seed_states = out.outputs[:, -1:].detach()
+            out.hidden = hidden = tuple(h.detach() for h in out.hidden)
+        if isinstance(self.surrogate, AutoRegPDESurrogate):
+            self.surrogate.reencode_predictions = True
+        return rollouts
+
+    def training_step(self, batch, bidx):
+        states, actions, *_ = batch
+        rollouts = self.tbptt_forward(states, actions)
+
+        outputs = torch.cat([r.outputs for r in rollouts], dim=1)
+        outdeltas = torch.cat([r.deltas for r in rollouts], dim=1)[:, :-1]
+        deltas = self.undscaling(torch.diff(states, dim=1) / self.delta)
+        if self.training_mode == "delta":
+            loss = self.loss(outdeltas, deltas)
+        else:
+            decoded = torch.cat((states[:, :1], outputs[:, :-1]), dim=1)
+            loss = self.loss(decoded, states)
+        hsteploss = loss.mean(dim=(0, 2, 3))
+        loss = loss.mean()
+
+        self.log("Train Loss", loss.detach(), on_step=False, on_epoch=True)
+        self.log("Train Mean Delta Output", outdeltas.detach().mean(), on_step=False, on_epoch=True)
+        self.log("Train Std. Delta Output", outdeltas.detach().std(), on_step=False, on_epoch=True)
+        self.log("Train Mean Delta", deltas.detach().mean(), on_step=False, on_epoch=True)
+        self.log("Train Std. Delta", deltas.detach().std(), on_step=False, on_epoch=True)
+
+        return {"loss": loss, "hsteploss": hsteploss.detach(), "outputs": outputs.detach(),
+                "actions": actions.detach(), "states": states.detach(), "outdeltas": outdeltas.detach(),
+                "deltas": deltas.detach()}
+
+    # -- validation / test: one un-truncated rollout ------------------------------------------
+    def validation_step(self, batch, bidx):
+        states, actions, *_ = batch
+        out = self._full_rollout(states, actions)
+        decoded = torch.cat((states[:, :1], out.outputs[:, :-1]), dim=1)  # IC-augmented prediction
+        outdeltas = out.deltas[:, :-1]
+        deltas = self.undscaling(torch.diff(states, dim=1) / self.delta)
+        self.log("Val. Delta Loss", self.loss(outdeltas, deltas).detach().mean(), on_step=False, on_epoch=True)
+        self.log("Val. Scaled Loss", self.loss(decoded, states).mean(), on_step=False, on_epoch=True)
+
+        states = self.stransf.otransf.Inverse(states)
+        decoded = self.stransf.otransf.Inverse(decoded)
+        loss = self.loss(decoded, states)
+        hsteploss = loss.detach().mean(dim=(0, 2, 3))
+        loss = loss.mean()
+        self.log("Val. Loss", loss, on_step=False, on_epoch=True)
+        return {"loss": loss.detach(), "hsteploss": hsteploss.detach(), "outputs": decoded.detach(),
+                "actions": actions.detach(), "states": states.detach(), "outdeltas": outdeltas.detach(),
+                "deltas": deltas.detach()}
+
+    def test_step(self, batch, bidx):
+        states, actions, *_ = batch
+        out = self._full_rollout(states, actions)
+        outputs = torch.cat((states[:, :1], out.outputs[:, :-1]), dim=1)
+        states = self.stransf.otransf.Inverse(states).detach().cpu()
+        outputs = self.stransf.otransf.Inverse(outputs).detach().cpu()
+        actions = actions.detach().cpu()
+
+        def norms(a, b, dims, p):
+            return torch.norm(a - b, p=p, dim=dims[0]), torch.norm(b, p=p, dim=dims[0])
+
+        err1, ref1 = norms(outputs, states, (3,), 1)
+        err2, ref2 = norms(outputs, states, (3,), 2)
+        tm = lambda v: v.mean(dim=(0, 2)).numpy()
+        data = {"MSE": self.loss(outputs, states).mean().numpy(), "l1_loss": tm(err1), "l2_loss": tm(err2),
+                "l1_loss_scaled": tm(err1 / ref1), "l2_loss_scaled": tm(err2 / ref2),
+                "nrmse": tm(err2 ** 2 / ref2 ** 2)}
+
+        # reward estimates on true vs predicted states (env.forcing / env.reward_func, per sample)
+        b, t, ac, ah = actions.shape
+        _, _, sc, sh = states.shape
+        flat = lambda v, c, h: v.reshape(b * t, c, h)
+        phi = BatchTransform(self.env.forcing)(self.stransf.atransf.Inverse(flat(actions, ac, ah)))
+        rew = lambda vals: torch.stack([torch.as_tensor(self.env.reward_func(v, p)) for v, p in zip(vals, phi)],
+                                       dim=0).reshape(b, t)
+        rews, pred_rews = rew(flat(states, sc, sh)), rew(flat(outputs, sc, sh))
+        e1, r1 = torch.norm(rews - pred_rews, p=1, dim=0), torch.norm(rews, p=1, dim=0)
+        e2, r2 = torch.norm(rews - pred_rews, p=2, dim=0), torch.norm(rews, p=2, dim=0)
+        data.update({"l1_loss_rews": e1.numpy(), "l2_loss_rews": e2.numpy(), "l1_loss_scaled_rews": (e1 / r1).numpy(),
+                     "l2_loss_scaled_rews": (e2 / r2).numpy(), "nrmse_rews": (e2 ** 2 / r2 ** 2).numpy()})
+
+        # spatial derivatives (env.rhs) of true vs predicted states
+        def derivatives(vals):
+            d = [self.env.rhs(v, p)[1] for v, p in zip(vals.numpy(), phi.numpy())]
+            d = torch.as_tensor(np.asarray([list(x) for x in d]))
+            return d.reshape(b, t, *d.shape[1:])
+        dv, pdv = derivatives(flat(states, sc, sh)), derivatives(flat(outputs, sc, sh))
+        d1, n1 = torch.norm(dv - pdv, p=1, dim=4), torch.norm(dv, p=1, dim=4)
+        d2, n2 = torch.norm(dv - pdv, p=2, dim=4), torch.norm(dv, p=2, dim=4)
+        dm = lambda v: v.mean(dim=(0, 3))
+        named = {"l1_loss_derivs": dm(d1), "l2_loss_derivs": dm(d2), "l1_loss_scaled_derivs": dm(d1 / n1),
+                 "l2_loss_scaled_derivs": dm(d2 / n2), "nrms_derivs": dm(d2 ** 2 / n2 ** 2)}
+        for name, table in named.items():
+            for idx, column in enumerate(table.T):
+                data[f"{name}-derivative-{idx}"] = column
+        data.update({"states": states.numpy(), "outputs": outputs.numpy(), "actions": actions.numpy()})
+        return data
+
+    def configure_optimizers(self):
+        optimizer = torch.optim.Adam(self.surrogate.parameters(), lr=self.lr)
+        scheduler = torch.optim.lr_scheduler.StepLR(optimizer, step_size=self.step_size, gamma=self.lr_gamma)
+        return [optimizer], [{"scheduler": scheduler, "interval": "epoch"}]

@@ -31,11 +31,25 @@ def _from_tensor(t, was_numpy):
     return t.detach().numpy() if was_numpy else t
 
 
+_DEVICE_COPIES = {}
+
+
 def _on(stat, like):
-    """Statistic tensor on the device of ``like`` (no copy when already there)."""
-    if isinstance(stat, torch.Tensor) and isinstance(like, torch.Tensor) and stat.device != like.device:
-        return stat.to(like.device)
-    return stat
+    """Statistic tensor on the device of ``like``.  Device copies are cached per (source tensor,
+    device) -- the source is kept alive in the cache entry, so an entry can only be hit by the very
+    tensor it was made from; re-assigned statistics (``update`` always re-assigns) miss and are
+    copied afresh.  This keeps host->device copies out of steady-state steps (and therefore out of
+    HIP-graph capture, where they are illegal)."""
+    if not (isinstance(stat, torch.Tensor) and isinstance(like, torch.Tensor)) or stat.device == like.device:
+        return stat
+    key = (id(stat), like.device)
+    hit = _DEVICE_COPIES.get(key)
+    if hit is None or hit[0] is not stat:
+        if len(_DEVICE_COPIES) > 256:
+            _DEVICE_COPIES.clear()
+        hit = (stat, stat.to(like.device))
+        _DEVICE_COPIES[key] = hit
+    return hit[1]
 
 
 class _InverseView:

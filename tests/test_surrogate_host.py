@@ -1,0 +1,166 @@
+"""Surrogate mirror (pdecontrol.*) on CPU against golden tensors captured from the reference.
+The CPU path is plain torch, i.e. the fp32 torch reference the GPU kernels are compared to."""
+import numpy as np
+import pytest
+import torch
+
+import pdecontrol.architectures as architectures
+from pdecontrol.architectures import KSAutoRegConvolutionalLSTM, KSAutoRegConvolutionalLSTMN
+from pdecontrol.mbrl.types import ModelRollout
+from pdecontrol.surrogates.surrogate import AutoRegPDESurrogate, PDEEnsemble, action_and_target_indices
+from pdecontrol.surrogates.training import PDETrainingModule
+from pdegym.common.transforms import BatchTransform, Normalize
+
+
+def build(dscaling=None, undscaling=None, factory_cls=KSAutoRegConvolutionalLSTM, **model_kw):
+    torch.manual_seed(0)
+    factory = factory_cls()
+    surrogate = factory.surrogate(delta=0.25, dscaling=dscaling, tau=5, **factory.model(**model_kw))
+    module = PDETrainingModule(surrogate=surrogate, loss=torch.nn.MSELoss(reduction="none"), tstep=0.25, delta=0.25,
+                               undscaling=undscaling, tau=5, tbtt=10)
+    return surrogate, module
+
+
+def test_registry_and_factory_api():
+    f = getattr(architectures, "KSAutoRegConvolutionalLSTM")()  # script.py:91 style lookup
+    d = f.defaults
+    assert set(d.keys()) == {"model", "surrogate", "training", "trainer", "curriculum"} and d.model == {}
+    model = f.model(N=64, L=22.0, cfg_steps=250)  # scenario kwargs are swallowed
+    assert set(model) == {"state_encoder", "state_decoder", "action_encoder", "transition_model"}
+    s = f.surrogate(delta=0.25, dscaling=None, tau=5, N=64, **model)
+    assert isinstance(s, AutoRegPDESurrogate)
+
+
+def test_state_dict_keys_init_and_param_count(sur_golden):
+    surrogate, _ = build()
+    sd = surrogate.state_dict()
+    keys = [k[3:] for k in sur_golden.files if k.startswith("sd/")]
+    assert list(sd.keys()) == keys
+    for k in keys:  # same construction order -> same RNG stream -> identical initial weights
+        np.testing.assert_array_equal(sd[k].numpy(), sur_golden["sd/" + k], err_msg=k)
+    assert sum(p.numel() for p in surrogate.parameters() if p.requires_grad) == int(sur_golden["n_trainable"]) == 9739
+    surrogate.load_state_dict({k: torch.from_numpy(sur_golden["sd/" + k]) for k in keys})  # checkpoints load
+
+
+def test_training_step_matches_reference_bitwise(sur_golden):
+    g = sur_golden
+    surrogate, module = build()
+    batch = (torch.from_numpy(g["b8_states"]), torch.from_numpy(g["b8_actions"]))
+    res = module.training_step(batch, 0)
+    assert set(res) == {"loss", "hsteploss", "outputs", "actions", "states", "outdeltas", "deltas"}
+    res["loss"].backward()
+    assert res["loss"].item() == g["b8_loss"]
+    for key in ("hsteploss", "outputs", "outdeltas", "deltas"):
+        np.testing.assert_array_equal(res[key].numpy(), g["b8_" + key], err_msg=key)
+    assert res["outputs"].shape == (8, 20, 1, 64) and res["outdeltas"].shape == (8, 19, 1, 64)
+    for k, p in surrogate.named_parameters():
+        if p.grad is not None:
+            np.testing.assert_array_equal(p.grad.numpy(), g["b8_grad/" + k], err_msg=k)
+    assert "Train Loss" in module.logged
+    # one Adam step (configure_optimizers) and the loss again
+    opt = module.configure_optimizers()[0][0]
+    opt.step()
+    opt.zero_grad()
+    assert module.training_step(batch, 1)["loss"].item() == g["b8_loss_after_adam"]
+
+
+def test_training_step_with_normalize_scaling(sur_golden):
+    g = sur_golden
+    norm = Normalize(aggregate=True, batched=True)
+    norm.mean, norm.var, norm.count = torch.full((1, 1, 1), 0.01), torch.full((1, 1, 1), 0.5), 100
+    und = BatchTransform(norm)
+    surrogate, module = build(dscaling=und.Inverse, undscaling=und)
+    res = module.training_step((torch.from_numpy(g["b8_states"]), torch.from_numpy(g["b8_actions"])), 0)
+    res["loss"].backward()
+    assert res["loss"].item() == g["b8n_loss"]
+    for key in ("hsteploss", "outputs", "outdeltas", "deltas"):
+        np.testing.assert_array_equal(res[key].numpy(), g["b8n_" + key], err_msg=key)
+    for k, p in surrogate.named_parameters():
+        if p.grad is not None:
+            np.testing.assert_array_equal(p.grad.numpy(), g["b8n_grad/" + k], err_msg=k)
+
+
+def test_known_answer_b64(sur_golden):
+    surrogate, module = build()
+    gen = torch.Generator().manual_seed(1)
+    s = torch.rand(64, 20, 1, 64, generator=gen) * 2 - 1
+    a = torch.rand(64, 20, 1, 64, generator=gen) * 2 - 1
+    res = module.training_step((s, a), 0)
+    res["loss"].backward()
+    assert res["loss"].item() == 10.806351661682129 == float(sur_golden["b64_loss"])
+    gn = torch.sqrt(sum((p.grad ** 2).sum() for p in surrogate.parameters() if p.grad is not None)).item()
+    np.testing.assert_allclose(gn, 1.3024945259094238, rtol=1e-6)
+    np.testing.assert_array_equal(res["hsteploss"].numpy(), sur_golden["b64_hsteploss"])
+
+
+def test_rollout_api_hidden_carry_and_inlatents(sur_golden):
+    g = sur_golden
+    surrogate, _ = build()
+    s, a = torch.from_numpy(g["b8_states"]), torch.from_numpy(g["b8_actions"])
+    with torch.no_grad():
+        times, targets = 0.25 * torch.arange(10), 0.25 * (torch.arange(10) + 1)
+        r1 = surrogate.rollout(states=s[:, :5], actions=a[:, :10], times=times, targets=targets, hidden=None)
+        r2 = surrogate.rollout(states=r1.outputs[:, -1, None], actions=a[:, 10:], times=times, targets=targets,
+                               hidden=r1.hidden)
+    assert isinstance(r1, ModelRollout) and isinstance(r1.hidden, tuple) and len(list(r1)) == 5
+    for name, got in (("outputs", r1.outputs), ("deltas", r1.deltas), ("inlatents", r1.inlatents),
+                      ("outlatents", r1.outlatents), ("H", r1.hidden[0]), ("C", r1.hidden[1])):
+        np.testing.assert_array_equal(got.numpy(), g["ro1_" + name], err_msg=name)
+    np.testing.assert_array_equal(r2.outputs.numpy(), g["ro2_outputs"])
+    np.testing.assert_array_equal(r2.hidden[0].numpy(), g["ro2_H"])
+    surrogate.reencode_predictions = False  # cheaper mode: same outputs, no inlatents
+    with torch.no_grad():
+        r3 = surrogate.rollout(states=s[:, :5], actions=a[:, :10], times=times, targets=targets, hidden=None)
+    assert r3.inlatents is None
+    np.testing.assert_array_equal(r3.outputs.numpy(), g["ro1_outputs"])
+
+
+@pytest.mark.parametrize("name", ["train10", "train15", "scalar", "warm5", "coarse"])
+def test_integer_index_paths_bit_exact(sur_golden, name):
+    g = sur_golden
+    aidx, tidx = action_and_target_indices(g[f"idx_{name}_times"], g[f"idx_{name}_targets"], 0.25)
+    np.testing.assert_array_equal(aidx.numpy(), g[f"idx_{name}_aidx"])
+    np.testing.assert_array_equal(tidx.numpy(), g[f"idx_{name}_tidx"])
+
+
+def test_validation_step_and_ensemble():
+    surrogate, module = build()
+    gen = torch.Generator().manual_seed(3)
+    s = torch.rand(4, 12, 1, 64, generator=gen)
+    a = torch.rand(4, 12, 1, 64, generator=gen)
+    with torch.no_grad():
+        res = module.validation_step((s, a), 0)
+    assert res["outputs"].shape == (4, 12, 1, 64) and "Val. Loss" in module.logged
+    torch.testing.assert_close(res["outputs"][:, 0], s[:, 0])
+    _, m2 = build()
+    ens = PDEEnsemble([module, m2], num_elites=1)
+    ens.update_elites([0.7, 0.2])
+    assert ens.elite_idx == [1]
+    np.random.seed(0)
+    with torch.no_grad():
+        out = ens.rollout(s[:, :5], a[:, :5], 0.25 * torch.arange(5), torch.tensor(1.25))
+        ref = m2.surrogate.rollout(s[:, :5], a[:, :5], 0.25 * torch.arange(5), torch.tensor(1.25))
+    torch.testing.assert_close(out.outputs, ref.outputs)  # only elite #1 can be chosen
+    assert len(out.hidden) == 2
+
+
+def test_size_parametrised_factory_n256():
+    surrogate, module = build(factory_cls=KSAutoRegConvolutionalLSTMN, N=256)
+    gen = torch.Generator().manual_seed(3)
+    s = torch.rand(2, 20, 1, 256, generator=gen)
+    a = torch.rand(2, 20, 1, 256, generator=gen)
+    res = module.training_step((s, a), 0)
+    res["loss"].backward()
+    assert res["outputs"].shape == (2, 20, 1, 256) and torch.isfinite(res["loss"])
+    s64, _ = build(factory_cls=KSAutoRegConvolutionalLSTMN, N=64)
+    ref, _ = build()
+    for (k1, v1), (k2, v2) in zip(s64.state_dict().items(), ref.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)
+
+
+def test_tbtt_must_exceed_tau():
+    torch.manual_seed(0)
+    f = KSAutoRegConvolutionalLSTM()
+    s = f.surrogate(delta=0.25, dscaling=None, tau=5, **f.model())
+    with pytest.raises(AssertionError):
+        PDETrainingModule(surrogate=s, loss=torch.nn.MSELoss(reduction="none"), tstep=0.25, delta=0.25, tau=5, tbtt=5)
