@@ -64,12 +64,12 @@ def cpu_baseline(E, N, L, target_seconds=12.0):
     u0 = rs.uniform(-0.4, 0.4, (E, N))
     act = np.random.RandomState(99).uniform(-1, 1, (E, 4)).astype(np.float32)
     phi = ko.phi_from_actions(act, forcing_matrix(L, N))
-    ko.step(u0[:cores], phi[:cores], L / N, DT, 10, nthreads=cores)  # spin up the thread pool
-    nsub = 25
+    ko.step(u0, phi, L / N, DT, 50, nthreads=cores)  # spin up the thread pool, warm caches
+    nsub = 500
     t0 = time.perf_counter()
     ko.step(u0, phi, L / N, DT, nsub, nthreads=cores)
     probe = time.perf_counter() - t0
-    nsub = int(max(25, min(CFG_STEPS * 800, nsub * target_seconds / max(probe, 1e-6))))
+    nsub = int(max(250, min(CFG_STEPS * 400, nsub * target_seconds / max(probe, 1e-6))))
     t0 = time.perf_counter()
     ko.step(u0, phi, L / N, DT, nsub, nthreads=cores)
     dt = time.perf_counter() - t0

@@ -1,0 +1,13 @@
+#!/usr/bin/env python3
+"""Condense a rocprofv3 *_kernel_stats.csv into a fixed-width table (top 25 kernels + totals)."""
+import csv
+import sys
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+tot_ns = sum(float(r["TotalDurationNs"]) for r in rows)
+tot_calls = sum(int(r["Calls"]) for r in rows)
+print(f"# {sys.argv[1].split('/')[-1]}: {len(rows)} distinct kernels, {tot_calls} launches, {tot_ns/1e6:.3f} ms GPU time")
+print("%-70s %8s %14s %12s %7s %10s %10s" % ("Name", "Calls", "TotalNs", "AvgNs", "Pct", "MinNs", "MaxNs"))
+for r in rows[:25]:
+    print("%-70s %8s %14s %12.0f %7.2f %10s %10s" % (r["Name"][:70], r["Calls"], r["TotalDurationNs"],
+                                                  float(r["AverageNs"]), float(r["Percentage"]), r["MinNs"], r["MaxNs"]))
