@@ -163,6 +163,79 @@ __device__ __forceinline__ double rhs_point(const double* w, const double* q, in
     }
 }
 
+
+// FAST-mode rhs for a tile of TJ consecutive points, written op-major ("vector across the tile") so that
+// consecutive instructions are independent: one wave per SIMD cannot hide the fp64 dependent-issue
+// latency by switching waves, the instruction stream itself has to.
+template <int TJ>
+__device__ __forceinline__ void rhs_tile_fast(const double* w, const double* q, int c0, const double* phi,
+                                              const StepArgs& a, double* k) {
+    double lin[TJ], s1[TJ], s2[TJ], s3[TJ], s4[TJ], bw[TJ], fw[TJ];
+#pragma unroll
+    for (int t = 0; t < TJ; ++t) s1[t] = w[c0 + t - 1] + w[c0 + t + 1];
+#pragma unroll
+    for (int t = 0; t < TJ; ++t) s2[t] = w[c0 + t - 2] + w[c0 + t + 2];
+#pragma unroll
+    for (int t = 0; t < TJ; ++t) lin[t] = __builtin_fma(a.c_lin[0], w[c0 + t], phi[t]);
+#pragma unroll
+    for (int t = 0; t < TJ; ++t) bw[t] = (25.0 / 12) * q[c0 + t];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < TJ; ++t) s3[t] = w[c0 + t - 3] + w[c0 + t + 3];
+#pragma unroll
+    for (int t = 0; t < TJ; ++t) lin[t] = __builtin_fma(a.c_lin[1], s1[t], lin[t]);
+#pragma unroll
+    for (int t = 0; t < TJ; ++t) fw[t] = __builtin_fma(4.0, q[c0 + t + 1], -bw[t]);  // fw holds MINUS the forward sum
+#pragma unroll
+    for (int t = 0; t < TJ; ++t) bw[t] = __builtin_fma(-4.0, q[c0 + t - 1], bw[t]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < TJ; ++t) s4[t] = w[c0 + t - 4] + w[c0 + t + 4];
+#pragma unroll
+    for (int t = 0; t < TJ; ++t) lin[t] = __builtin_fma(a.c_lin[2], s2[t], lin[t]);
+#pragma unroll
+    for (int t = 0; t < TJ; ++t) fw[t] = __builtin_fma(-3.0, q[c0 + t + 2], fw[t]);
+#pragma unroll
+    for (int t = 0; t < TJ; ++t) bw[t] = __builtin_fma(3.0, q[c0 + t - 2], bw[t]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < TJ; ++t) lin[t] = __builtin_fma(a.c_lin[3], s3[t], lin[t]);
+#pragma unroll
+    for (int t = 0; t < TJ; ++t) fw[t] = __builtin_fma(4.0 / 3, q[c0 + t + 3], fw[t]);
+#pragma unroll
+    for (int t = 0; t < TJ; ++t) bw[t] = __builtin_fma(-4.0 / 3, q[c0 + t - 3], bw[t]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < TJ; ++t) lin[t] = __builtin_fma(a.c_lin[4], s4[t], lin[t]);
+#pragma unroll
+    for (int t = 0; t < TJ; ++t) fw[t] = __builtin_fma(-0.25, q[c0 + t + 4], fw[t]);
+#pragma unroll
+    for (int t = 0; t < TJ; ++t) bw[t] = __builtin_fma(0.25, q[c0 + t - 4], bw[t]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < TJ; ++t) {
+        const double sel = (w[c0 + t] < 0.0) ? fw[t] : bw[t];  // u == 0 selects the backward stencil
+        k[t] = __builtin_fma(a.mh_inv_dx, sel, lin[t]);
+    }
+}
+
+template <int P>
+__host__ __device__ constexpr int tile_of() { return P % 4 == 0 ? 4 : (P % 3 == 0 ? 3 : (P % 2 == 0 ? 2 : 1)); }
+
+
+template <int P, bool EXACT>
+__device__ __forceinline__ void eval_rhs(const double* w, const double* q, const double (&phi)[P],
+                                         const StepArgs& a, double (&kk)[P]) {
+    if constexpr (EXACT) {
+#pragma unroll
+        for (int j = 0; j < P; ++j) kk[j] = rhs_point<true>(w, q, 4 + j, phi[j], a);
+    } else {
+        constexpr int TJ = tile_of<P>();
+#pragma unroll
+        for (int jb = 0; jb < P; jb += TJ) rhs_tile_fast<TJ>(w, q, 4 + jb, &phi[jb], a, &kk[jb]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // fused register-resident stepper
 // ------------------------------------------------------------------------------------------
@@ -251,16 +324,17 @@ __global__ void __launch_bounds__(256) ks_rk4_fused(const StepArgs a) {
 
     double racc = 0.0;
     for (long s = 0; s < a.n_substeps; ++s) {
-        double acc[P], us[P], usn[P], w[P + 8], q[P + 8];
+        double acc[P], us[P], usn[P], w[P + 8], q[P + 8], kk[P];
         // ---- stage 1 (k1 at u) + reward term of this sub-step ----
         build_window<P, G, HALO, EXACT>(halo, u, w);
 #pragma unroll
         for (int i = 0; i < P + 8; ++i) q[i] = w[i] * w[i];
 #pragma unroll
         for (int j = 0; j < P; ++j) racc += q[4 + j];
+        eval_rhs<P, EXACT>(w, q, phi, a, kk);
 #pragma unroll
         for (int j = 0; j < P; ++j) {
-            const double k = rhs_point<EXACT>(w, q, 4 + j, phi[j], a);
+            const double k = kk[j];
             if constexpr (EXACT) {
                 acc[j] = k;
                 usn[j] = u[j] + a.dt * k / 2.0;
@@ -275,9 +349,10 @@ __global__ void __launch_bounds__(256) ks_rk4_fused(const StepArgs a) {
         build_window<P, G, HALO, EXACT>(halo, us, w);
 #pragma unroll
         for (int i = 0; i < P + 8; ++i) q[i] = w[i] * w[i];
+        eval_rhs<P, EXACT>(w, q, phi, a, kk);
 #pragma unroll
         for (int j = 0; j < P; ++j) {
-            const double k = rhs_point<EXACT>(w, q, 4 + j, phi[j], a);
+            const double k = kk[j];
             if constexpr (EXACT) {
                 acc[j] = acc[j] + 2.0 * k;
                 usn[j] = u[j] + a.dt * k / 2.0;
@@ -292,9 +367,10 @@ __global__ void __launch_bounds__(256) ks_rk4_fused(const StepArgs a) {
         build_window<P, G, HALO, EXACT>(halo, us, w);
 #pragma unroll
         for (int i = 0; i < P + 8; ++i) q[i] = w[i] * w[i];
+        eval_rhs<P, EXACT>(w, q, phi, a, kk);
 #pragma unroll
         for (int j = 0; j < P; ++j) {
-            const double k = rhs_point<EXACT>(w, q, 4 + j, phi[j], a);
+            const double k = kk[j];
             if constexpr (EXACT) {
                 acc[j] = acc[j] + 2.0 * k;
                 usn[j] = u[j] + a.dt * k;
@@ -309,9 +385,10 @@ __global__ void __launch_bounds__(256) ks_rk4_fused(const StepArgs a) {
         build_window<P, G, HALO, EXACT>(halo, us, w);
 #pragma unroll
         for (int i = 0; i < P + 8; ++i) q[i] = w[i] * w[i];
+        eval_rhs<P, EXACT>(w, q, phi, a, kk);
 #pragma unroll
         for (int j = 0; j < P; ++j) {
-            const double k = rhs_point<EXACT>(w, q, 4 + j, phi[j], a);
+            const double k = kk[j];
             if constexpr (EXACT) {
                 acc[j] = acc[j] + k;
                 u[j] = u[j] + a.dt * acc[j] / 6.0;

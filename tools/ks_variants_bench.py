@@ -42,12 +42,13 @@ def run(E, N, L, variant, block, mode, nsub=250, reps=5):
 
 
 if __name__ == "__main__":
-    only = sys.argv[1:] or None
+    modes = [a for a in sys.argv[1:] if a in ("fast", "exact")] or ["fast", "exact"]
+    skip_lds = "nolds" in sys.argv[1:]
     for (E, N, L) in CASES:
-        for mode in ("fast", "exact"):
+        for mode in modes:
             for v in VARIANTS:
                 for block in (64, 256):
-                    if v == "lds" and block == 64 and N > 64:
+                    if v == "lds" and (skip_lds or (block == 64 and N > 64)):
                         continue
                     try:
                         rate, dt, lay = run(E, N, L, v, block, mode)
