@@ -57,18 +57,9 @@ def first_loss(device, B):
         return float(module.training_step(synthetic_batch(B=B, device=device), 0)["loss"])
 
 
-def run(device, steps=50, warmup=5, B=64, cpu_steps=3):
+def time_graphed(device, batch, steps, warmup):
     from pdecontrol.surrogates.graph_step import GraphedTBPTTStep
-    batch = synthetic_batch(B=B, device=device)
-    res = {"unit": "seqs/s", "config": {"factory": "KSAutoRegConvolutionalLSTM", "B": B, "T": 20, "tau": 5,
-                                        "tbtt": 10, "N": 64, "dtype": "f32", "optimizer": "Adam lr 1e-3",
-                                        "step": "training_step + backward + Adam"}}
-    module = build_module(device)
-    dt, _ = time_eager(module, batch, steps=10, warmup=2)
-    res["eager"] = {"value": B / dt, "ms_per_step": dt * 1e3}
-
-    module = build_module(device)
-    graphed = GraphedTBPTTStep(module, tuple(batch[0].shape))
+    graphed = GraphedTBPTTStep(build_module(device), tuple(batch[0].shape))
     graphed.step(*batch)
     for _ in range(warmup):
         graphed.step()
@@ -78,13 +69,36 @@ def run(device, steps=50, warmup=5, B=64, cpu_steps=3):
         graphed.step()
     torch.cuda.synchronize(device)
     dt = (time.perf_counter() - t0) / steps
-    res["hip_graph"] = {"value": B / dt, "ms_per_step": dt * 1e3, "steps": steps,
-                        "loss_after_training": float(graphed.result["loss"].detach())}
-    res["value"] = res["hip_graph"]["value"]
+    return {"value": batch[0].shape[0] / dt, "ms_per_step": dt * 1e3, "steps": steps,
+            "loss_after_training": float(graphed.result["loss"].detach())}
+
+
+def run(device, steps=50, warmup=5, B=64, cpu_steps=3):
+    batch = synthetic_batch(B=B, device=device)
+    res = {"unit": "seqs/s", "config": {"factory": "KSAutoRegConvolutionalLSTM", "B": B, "T": 20, "tau": 5,
+                                        "tbtt": 10, "N": 64, "dtype": "f32", "optimizer": "Adam lr 1e-3",
+                                        "step": "training_step + backward + Adam"}}
+    module = build_module(device)
+    dt, _ = time_eager(module, batch, steps=10, warmup=2)
+    res["eager"] = {"value": B / dt, "ms_per_step": dt * 1e3}
+
+    res["hip_graph"] = time_graphed(device, batch, steps, warmup)
+
+    # fused HIP kernels (libsurrogate_hip.so): 2 encoder launches + 1 launch per time step, each way
+    from pdecontrol.surrogates import ops
+    try:
+        ops.enable_fused(True)
+        res["hip_graph_fused"] = time_graphed(device, batch, steps * 4, warmup)
+        loss_fused = first_loss(device, B)
+    finally:
+        ops.enable_fused(False)
+    res["value"] = res["hip_graph_fused"]["value"]
 
     # parity of the measured configuration: first-step loss GPU vs CPU (contract: 1e-5 relative)
     loss_gpu, loss_cpu = first_loss(device, B), first_loss("cpu", B)
-    res["first_loss"] = {"gpu": loss_gpu, "cpu": loss_cpu, "rel_diff": abs(loss_gpu - loss_cpu) / abs(loss_cpu)}
+    res["first_loss"] = {"gpu": loss_gpu, "gpu_fused": loss_fused, "cpu": loss_cpu,
+                         "rel_diff": abs(loss_gpu - loss_cpu) / abs(loss_cpu),
+                         "rel_diff_fused": abs(loss_fused - loss_cpu) / abs(loss_cpu)}
 
     # CPU baseline: the same nn.Module tree / training_step / Adam on torch CPU kernels (what the
     # reference runs), at 1 thread (the reference's regime for these tiny ops) and at 16 threads

@@ -24,6 +24,11 @@ def fused_enabled():
     return _FUSED["enabled"]
 
 
+def use_fused(tensor):
+    """True when the fused HIP rollout (hipops.fused_rollout) should handle this tensor."""
+    return _FUSED["enabled"] and tensor.is_cuda
+
+
 def conv_act_norm(x, conv, activation, layernorm):
     """layernorm(activation(conv(x))) for nn.Conv1d (circular) / nn.ConvTranspose1d modules."""
     y = activation(conv(x))
@@ -32,9 +37,6 @@ def conv_act_norm(x, conv, activation, layernorm):
 
 def lstm_cell(x, h, c, cell):
     """Convolutional LSTM cell (transition.py CNNLSTMCell.forward): returns (h', c')."""
-    if _FUSED["enabled"] and x.is_cuda:
-        from pdecontrol.surrogates import hipops
-        return hipops.lstm_cell(x, h, c, cell)
     gi = cell.Wxi(x) + cell.Whi(h)
     gf = cell.Wxf(x) + cell.Whf(h)
     gc = cell.Wxc(x) + cell.Whc(h)

@@ -17,7 +17,7 @@ import torch
 from torch import nn
 
 from pdecontrol.mbrl.types import ModelRollout
-from pdecontrol.surrogates import utils
+from pdecontrol.surrogates import ops, utils
 from pdecontrol.surrogates.transition import TransitionModel
 from pdegym.common.transforms import BatchTransform, Identity
 
@@ -107,6 +107,10 @@ class AutoRegPDESurrogate(_EncDecSurrogate):
 
     def rollout(self, states: torch.Tensor, actions: torch.Tensor, times: torch.Tensor, targets: torch.Tensor,
                 hidden=None, **kwargs) -> ModelRollout:
+        if ops.use_fused(states):
+            # one launch per module instead of ~60 per time step (no inlatents in this mode)
+            from pdecontrol.surrogates import hipops
+            return hipops.fused_rollout(self, states, actions, times, targets, hidden)
         n_given = states.size(1)
         lstates = self.state_encoder(states)
         aidx, tidx = action_and_target_indices(times, targets, self.delta)

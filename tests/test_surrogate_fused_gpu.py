@@ -1,0 +1,157 @@
+"""Fused HIP surrogate kernels (libsurrogate_hip.so) against the plain torch path on the same GPU,
+and the fused TBPTT step against the golden tensors from the reference (loss within 1e-5 rel)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda", 0)
+
+
+def _build(dev, scaled=True, N=64, seed=0):
+    from pdecontrol.architectures import KSAutoRegConvolutionalLSTMN
+    from pdecontrol.surrogates.training import PDETrainingModule
+    from pdegym.common.transforms import BatchTransform, Normalize
+    torch.manual_seed(seed)
+    und = None
+    if scaled:
+        norm = Normalize(aggregate=True, batched=True)
+        norm.mean, norm.var, norm.count = torch.full((1, 1, 1), 0.01), torch.full((1, 1, 1), 0.5), 100
+        und = BatchTransform(norm)
+    f = KSAutoRegConvolutionalLSTMN()
+    s = f.surrogate(delta=0.25, dscaling=None if und is None else und.Inverse, tau=5, **f.model(N=N))
+    m = PDETrainingModule(surrogate=s, loss=torch.nn.MSELoss(reduction="none"), tstep=0.25, delta=0.25,
+                          undscaling=und, tau=5, tbtt=10)
+    # non-trivial LayerNorm affine parameters and biases so every gradient path is exercised
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for name, p in m.surrogate.named_parameters():
+            if "norm" in name or name.endswith(".bias"):
+                p.add_(0.3 * torch.randn(p.shape, generator=g))
+    return m.to(dev)
+
+
+def _grads(module):
+    return {k: p.grad.detach().clone() for k, p in module.surrogate.named_parameters() if p.grad is not None}
+
+
+def _zero(module):
+    for p in module.surrogate.parameters():
+        if p.grad is not None:
+            p.grad.zero_()
+
+
+def _close(a, b, rtol=2e-4, atol_scale=2e-5, msg=""):
+    a, b = a.detach().cpu().numpy(), b.detach().cpu().numpy()
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol_scale * max(1.0, np.abs(b).max()), err_msg=msg)
+
+
+@pytest.mark.parametrize("which", ["state_encoder", "action_encoder"])
+@pytest.mark.parametrize("N", [64, 256])
+def test_fused_encoder_forward_backward(dev, which, N):
+    from pdecontrol.surrogates import hipops
+    m = _build(dev, N=N)
+    enc = getattr(m.surrogate, which).model
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(7, 1, N, generator=g).to(dev).requires_grad_(True)
+    up = torch.randn(7, enc.block_l2.conv3x3_l1.out_channels, N // 4, generator=g).to(dev)
+    z_ref = enc(x)
+    z_ref.backward(up)
+    ref_g, dx_ref = _grads(m), x.grad.clone()
+    _zero(m)
+    x.grad = None
+    packs = hipops.packs_for(m.surrogate, N)
+    pack = packs.state_enc if which == "state_encoder" else packs.action_enc
+    z = hipops.encode(x, pack, packs.anchor)
+    _close(z, z_ref, msg="forward")
+    z.backward(up)
+    _close(x.grad, dx_ref, msg="dx")
+    got = _grads(m)
+    for k, v in ref_g.items():
+        if k.startswith(which):
+            _close(got[k], v, msg=k)
+
+
+@pytest.mark.parametrize("N", [64, 256])
+def test_fused_step_forward_backward(dev, N):
+    from pdecontrol.surrogates import hipops
+    m = _build(dev, N=N)
+    sur = m.surrogate
+    hq = N // 4
+    g = torch.Generator().manual_seed(7)
+    mk = lambda *shape: torch.randn(*shape, generator=g).to(dev).requires_grad_(True)
+    xlat, h_in, c_prev, base = mk(5, 4, hq), mk(5, 16, hq), mk(5, 16, hq), mk(5, 1, N)
+    ups = [torch.randn(5, 16, hq, generator=g).to(dev), torch.randn(5, 16, hq, generator=g).to(dev),
+           torch.randn(5, 1, N, generator=g).to(dev), torch.randn(5, 1, N, generator=g).to(dev)]
+
+    def torch_step():
+        H, C = sur.transition_model.cnnlstmcell(xlat, h_in, c_prev)
+        d = sur.state_decoder.model(H)
+        out = base + sur.delta * sur.dscaling(d)
+        return H, C, d, out
+
+    outs_ref = torch_step()
+    torch.autograd.backward(outs_ref, ups)
+    ref_g = _grads(m)
+    ref_in = [t.grad.clone() for t in (xlat, h_in, c_prev, base)]
+    _zero(m)
+    for t in (xlat, h_in, c_prev, base):
+        t.grad = None
+    packs = hipops.packs_for(sur, N)
+    outs = hipops.rollout_step(xlat, h_in, c_prev, base, packs.step, packs.anchor)
+    for name, a, b in zip(("H", "C", "d", "out"), outs, outs_ref):
+        _close(a, b, msg=name)
+    torch.autograd.backward(outs, ups)
+    for name, t, r in zip(("dxlat", "dh_in", "dc_prev", "dbase"), (xlat, h_in, c_prev, base), ref_in):
+        _close(t.grad, r, msg=name)
+    got = _grads(m)
+    for k, v in ref_g.items():
+        if k.startswith(("transition_model", "state_decoder")):
+            _close(got[k], v, msg=k)
+
+
+def test_fused_training_step_matches_unfused_and_golden(dev, sur_golden):
+    from pdecontrol.surrogates import ops
+    g = sur_golden
+    s, a = torch.from_numpy(g["b8_states"]).to(dev), torch.from_numpy(g["b8_actions"]).to(dev)
+    try:
+        for scaled, tag in ((False, "b8"), (True, "b8n")):
+            from test_surrogate_gpu import _module
+            m = _module(dev, scaled)
+            ops.enable_fused(True)
+            _zero(m)
+            res = m.training_step((s, a), 0)
+            res["loss"].backward()
+            ops.enable_fused(False)
+            rel = abs(res["loss"].item() - g[f"{tag}_loss"]) / abs(g[f"{tag}_loss"])
+            assert rel < 1e-5, rel
+            np.testing.assert_allclose(res["outputs"].cpu().numpy(), g[f"{tag}_outputs"], rtol=1e-3, atol=1e-4)
+            np.testing.assert_allclose(res["outdeltas"].cpu().numpy(), g[f"{tag}_outdeltas"], rtol=1e-3, atol=1e-4)
+            for k, p in m.surrogate.named_parameters():
+                if p.requires_grad:
+                    ref = g[f"{tag}_grad/" + k]
+                    np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=1e-2,
+                                               atol=3e-5 * max(1.0, np.abs(ref).max()), err_msg=k)
+    finally:
+        ops.enable_fused(False)
+
+
+def test_fused_hip_graph_training_matches_unfused(dev):
+    from pdecontrol.surrogates import ops
+    from pdecontrol.surrogates.bench_tbptt import build_module, synthetic_batch
+    from pdecontrol.surrogates.graph_step import GraphedTBPTTStep
+    batch = synthetic_batch(B=16, device=dev)
+    plain = GraphedTBPTTStep(build_module(dev), tuple(batch[0].shape))
+    l_plain = [float(plain.step(*batch)["loss"].detach()) for _ in range(4)]
+    try:
+        ops.enable_fused(True)
+        fused = GraphedTBPTTStep(build_module(dev), tuple(batch[0].shape))
+        l_fused = [float(fused.step(*batch)["loss"].detach()) for _ in range(4)]
+    finally:
+        ops.enable_fused(False)
+    np.testing.assert_allclose(l_fused, l_plain, rtol=3e-5)
+    assert l_fused[-1] < l_fused[0]
