@@ -3,18 +3,25 @@
  *
  * The reference runs the surrogate as ~60 tiny torch CPU ops per time step
  * (pdecontrol/surrogates/surrogate.py:97-119 -> transition.py:218-226 + models/cnn.py:126-145,35-70).
- * On an MI355X that shape is launch-latency bound, so the per-sample work of whole modules is fused:
+ * On an MI355X that shape is launch-latency bound, so whole modules are fused per sample:
  *
  *   sur_encoder_forward / _backward   3 x ResidualBlock (models/cnn.py:73-145) as built by
  *                                     architectures/autoreg.py:51-73: [M,1,N] -> [M,C3,N/4]
- *   sur_step_forward / _backward      one rollout step (surrogate.py:97-107): CNNLSTMCell
- *                                     (transition.py:218-226) + state decoder (autoreg.py:79-94)
- *                                     + integration  out = base + delta * (d * mul + add)
+ *   sur_chunk_forward / _backward     a whole TBPTT chunk of K rollout steps (surrogate.py:97-119):
+ *                                     per step CNNLSTMCell (transition.py:218-226) + state decoder
+ *                                     (autoreg.py:79-94) + integration out = base + delta*(d*mul+add);
+ *                                     teacher forcing on the first S steps (transition.py:274-279),
+ *                                     free running afterwards (:285-296).  The time loop runs INSIDE
+ *                                     the kernel: weights stay in LDS, hidden state in LDS, and the
+ *                                     backward kernel does the whole BPTT of the chunk in one launch.
+ *   sur_flush_*_grads                 reduces the per-workgroup partial gradient rows into the
+ *                                     parameter gradient tensors (deterministic, no atomics)
  *
- * One workgroup handles one sample with every activation in LDS; the backward kernels recompute
- * the forward intermediates from the saved inputs (nothing but module inputs/outputs touches HBM)
- * and accumulate the parameter gradients straight into the caller's gradient buffers with fp32
- * atomics (the buffers must be zeroed by the caller each step).
+ * One workgroup handles one sample with every activation in LDS; backward kernels recompute the
+ * forward intermediates from saved module inputs / hidden states.  Parameter gradients are summed
+ * over space and time inside the workgroup and added to that workgroup's own row of `partial`
+ * ([rows][sum(size)] fp32, caller-allocated, zero-initialised); the flush kernel sums the rows into
+ * g[] and re-zeroes them.
  *
  * All pointers are DEVICE pointers of contiguous fp32 tensors; launches are asynchronous on the
  * given hipStream_t.  Return 0 on success, negative on error (sur_last_error()).
@@ -29,45 +36,59 @@ extern "C" {
 /* parameter order inside one ResidualBlock */
 enum { SUR_RB_CONV1 = 0, SUR_RB_LN1_W, SUR_RB_LN1_B, SUR_RB_CONV2, SUR_RB_LN2_W, SUR_RB_LN2_B, SUR_RB_SKIP,
        SUR_RB_LN3_W, SUR_RB_LN3_B, SUR_RB_NPARAM };
+#define SUR_ENC_NPARAM (3 * SUR_RB_NPARAM)
 
 typedef struct sur_encoder_params {
-    const float* w[3 * SUR_RB_NPARAM]; /* weights, block-major                                  */
-    float* g[3 * SUR_RB_NPARAM];       /* gradient accumulators (same order) or NULL in forward  */
-    int c[4];                          /* channels: in, block0, block1, block2 (1,8,16,16)       */
-    int stride[3];                     /* 2, 2, 1                                                */
-    int n;                             /* input width N                                          */
+    const float* w[SUR_ENC_NPARAM]; /* weights, block-major                                     */
+    float* g[SUR_ENC_NPARAM];       /* gradient tensors (targets of sur_flush_encoder_grads)    */
+    int size[SUR_ENC_NPARAM];       /* element count of each parameter                           */
+    int c[4];                       /* channels: in, block0, block1, block2 (1,8,16,16)          */
+    int stride[3];                  /* 2, 2, 1                                                   */
+    int n;                          /* input width N                                             */
+    float* partial;                 /* [rows][sum(size)] partial gradient rows                   */
+    int rows;
 } sur_encoder_params;
 
-/* parameter order of the step kernel */
+/* parameter order of the chunk kernel */
 enum { SUR_ST_WXI = 0, SUR_ST_BXI, SUR_ST_WHI, SUR_ST_WXF, SUR_ST_BXF, SUR_ST_WHF, SUR_ST_WXC, SUR_ST_BXC,
        SUR_ST_WHC, SUR_ST_WXO, SUR_ST_BXO, SUR_ST_WHO,
        SUR_ST_DC0_W, SUR_ST_DC0_B, SUR_ST_LN0_W, SUR_ST_LN0_B, SUR_ST_DC1_W, SUR_ST_DC1_B, SUR_ST_LN1_W,
        SUR_ST_LN1_B, SUR_ST_CV2_W, SUR_ST_CV2_B, SUR_ST_LN2_W, SUR_ST_LN2_B, SUR_ST_CV3_W, SUR_ST_CV3_B,
        SUR_ST_NPARAM };
 
-typedef struct sur_step_params {
+typedef struct sur_chunk_params {
     const float* w[SUR_ST_NPARAM];
     float* g[SUR_ST_NPARAM];
-    int ca, cs;        /* latent action / state channels (4, 16)                         */
-    int hq;            /* latent width N/4                                                */
-    int c_mid;         /* channels after the 2nd transposed conv (8)                      */
-    float delta;       /* integration step                                                */
+    int size[SUR_ST_NPARAM];
+    int ca, cs;        /* latent action / state channels (4, 16)                            */
+    int hq;            /* latent width N/4                                                   */
+    int c_mid;         /* channels after the 2nd transposed conv (8)                         */
+    float delta;       /* integration step                                                   */
     float mul, add;    /* dscaling(d) = d * mul + add  (Normalize.Inverse with scalar stats) */
-} sur_step_params;
+    float* partial;    /* [rows][sum(size)]                                                  */
+    int rows;
+} sur_chunk_params;
 
 int sur_encoder_forward(void* stream, const sur_encoder_params* p, const float* x, int m, float* z);
-/* dx may be NULL (raw data input).  Accumulates into p->g[]. */
+/* dx may be NULL (raw data input).  Accumulates parameter gradients into p->partial. */
 int sur_encoder_backward(void* stream, const sur_encoder_params* p, const float* x, const float* dz, int m,
                          float* dx);
+int sur_flush_encoder_grads(void* stream, const sur_encoder_params* p);
 
-int sur_step_forward(void* stream, const sur_step_params* p, const float* xlat, const float* h_in,
-                     const float* c_prev, const float* base, int b, float* h_out, float* c_out, float* d_out,
-                     float* out);
-/* dd / dout / dh / dc: upstream gradients wrt d_out / out / h_out / c_out, each may be NULL (= 0).
- * dxlat / dh_in / dc_prev / dbase: outputs, each may be NULL.  Accumulates into p->g[]. */
-int sur_step_backward(void* stream, const sur_step_params* p, const float* xlat, const float* h_in,
-                      const float* c_prev, const float* dd, const float* dout, const float* dh, const float* dc,
-                      int b, float* dxlat, float* dh_in, float* dc_prev, float* dbase);
+/* Time-major tensors: xlat_t [K,B,ca,hq]; lstates_t [S,B,cs,hq] (encoded given states, S >= 1);
+ * states_t [S,B,1,N] (the given states: bases of the teacher-forced steps); h0, c0 [B,cs,hq].
+ * Outputs: h_all, c_all [K,B,cs,hq]; d_all, out_all [K,B,1,N]. */
+int sur_chunk_forward(void* stream, const sur_chunk_params* p, const float* xlat_t, const float* lstates_t,
+                      const float* states_t, const float* h0, const float* c0, int k, int s, int b, float* h_all,
+                      float* c_all, float* d_all, float* out_all);
+/* Upstream gradients (each may be NULL = 0): dd_all / dout_all [K,B,1,N] wrt d_all / out_all;
+ * dh_all / dc_all [K,B,cs,hq] wrt h_all / c_all.  Outputs (each may be NULL): dxlat_t [K,B,ca,hq],
+ * dlstates_t [S,B,cs,hq], dh0, dc0 [B,cs,hq].  Accumulates parameter gradients into p->partial. */
+int sur_chunk_backward(void* stream, const sur_chunk_params* p, const float* xlat_t, const float* lstates_t,
+                       const float* h0, const float* c0, const float* h_all, const float* c_all,
+                       const float* dd_all, const float* dout_all, const float* dh_all, const float* dc_all, int k,
+                       int s, int b, float* dxlat_t, float* dlstates_t, float* dh0, float* dc0);
+int sur_flush_chunk_grads(void* stream, const sur_chunk_params* p);
 
 const char* sur_last_error(void);
 

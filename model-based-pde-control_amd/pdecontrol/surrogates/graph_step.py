@@ -25,10 +25,18 @@ class GraphedTBPTTStep:
         self.actions = torch.zeros(action_shape or batch_shape, device=dev)
         self.distributed = distributed
         self.bucket = FlatGradBucket(module.surrogate.parameters())
-        self.opt = torch.optim.Adam(module.surrogate.parameters(), lr=lr if lr is not None else module.lr,
-                                    capturable=True)
+        self.lr = lr if lr is not None else module.lr
+        self.opt = self._make_adam()
         self.result = None
         self._capture(warmup)
+
+    def _make_adam(self):
+        """Adam as ONE multi-tensor kernel (fused=True) instead of ~3 tiny kernels per parameter."""
+        params = list(self.module.surrogate.parameters())
+        try:
+            return torch.optim.Adam(params, lr=self.lr, capturable=True, fused=True)
+        except (RuntimeError, TypeError, ValueError):
+            return torch.optim.Adam(params, lr=self.lr, capturable=True)
 
     def _fwd_bwd(self):
         self.bucket.zero_()
@@ -49,8 +57,7 @@ class GraphedTBPTTStep:
         with torch.no_grad():
             for p, s in zip(self.module.surrogate.parameters(), snap):
                 p.copy_(s)
-        self.opt = torch.optim.Adam(self.module.surrogate.parameters(), lr=self.opt.param_groups[0]["lr"],
-                                    capturable=True)
+        self.opt = self._make_adam()
         # Adam state must exist before capture: one throw-away step on zero grads, then reset
         self.bucket.zero_()
         self.opt.step()

@@ -1,11 +1,13 @@
 """ctypes binding + autograd glue of libsurrogate_hip.so (C ABI: include/surrogate_hip.h).
 
 ``fused_rollout`` is the GPU implementation of ``AutoRegPDESurrogate.rollout`` for the
-``KSAutoRegConvolutionalLSTM`` family: two encoder launches (all given states, all actions) and one
-launch per time step (ConvLSTM cell + decoder + integration), each with a matching backward
-launch.  Parameter gradients are accumulated by the kernels directly into ``param.grad`` (fp32
-atomics), so the autograd graph only carries activations; a zero-dim ``anchor`` tensor makes the
-custom Functions differentiable even when their data inputs are not.
+``KSAutoRegConvolutionalLSTM`` family: two encoder launches (all given states, all actions) and ONE
+launch for the whole chunk of time steps (ConvLSTM cell + decoder + integration per step, time loop
+inside the kernel), each with a matching backward launch.  Parameter gradients never pass through
+autograd: the backward kernels add them to per-workgroup rows of a partial buffer and a flush
+kernel -- queued to run when the backward pass ends -- reduces the rows into ``param.grad``.  The
+autograd graph only carries activations; a zero-dim ``anchor`` tensor makes the custom Functions
+differentiable even when their data inputs are not.
 
 There is no fallback in here: if the library is missing, ``load()`` raises.
 """
@@ -24,22 +26,26 @@ _fp = ctypes.c_void_p
 
 
 class EncoderParams(ctypes.Structure):
-    _fields_ = [("w", _fp * (3 * RB_NPARAM)), ("g", _fp * (3 * RB_NPARAM)), ("c", ctypes.c_int * 4),
-                ("stride", ctypes.c_int * 3), ("n", ctypes.c_int)]
+    _fields_ = [("w", _fp * (3 * RB_NPARAM)), ("g", _fp * (3 * RB_NPARAM)), ("size", ctypes.c_int * (3 * RB_NPARAM)),
+                ("c", ctypes.c_int * 4), ("stride", ctypes.c_int * 3), ("n", ctypes.c_int), ("partial", _fp),
+                ("rows", ctypes.c_int)]
 
 
-class StepParams(ctypes.Structure):
-    _fields_ = [("w", _fp * ST_NPARAM), ("g", _fp * ST_NPARAM), ("ca", ctypes.c_int), ("cs", ctypes.c_int),
-                ("hq", ctypes.c_int), ("c_mid", ctypes.c_int), ("delta", ctypes.c_float), ("mul", ctypes.c_float),
-                ("add", ctypes.c_float)]
+class ChunkParams(ctypes.Structure):
+    _fields_ = [("w", _fp * ST_NPARAM), ("g", _fp * ST_NPARAM), ("size", ctypes.c_int * ST_NPARAM),
+                ("ca", ctypes.c_int), ("cs", ctypes.c_int), ("hq", ctypes.c_int), ("c_mid", ctypes.c_int),
+                ("delta", ctypes.c_float), ("mul", ctypes.c_float), ("add", ctypes.c_float), ("partial", _fp),
+                ("rows", ctypes.c_int)]
 
 
+_EP, _CP, _i = ctypes.POINTER(EncoderParams), ctypes.POINTER(ChunkParams), ctypes.c_int
 SYMBOLS = (
-    ("sur_encoder_forward", [_fp, ctypes.POINTER(EncoderParams), _fp, ctypes.c_int, _fp]),
-    ("sur_encoder_backward", [_fp, ctypes.POINTER(EncoderParams), _fp, _fp, ctypes.c_int, _fp]),
-    ("sur_step_forward", [_fp, ctypes.POINTER(StepParams), _fp, _fp, _fp, _fp, ctypes.c_int, _fp, _fp, _fp, _fp]),
-    ("sur_step_backward", [_fp, ctypes.POINTER(StepParams), _fp, _fp, _fp, _fp, _fp, _fp, _fp, ctypes.c_int, _fp, _fp,
-                           _fp, _fp]),
+    ("sur_encoder_forward", [_fp, _EP, _fp, _i, _fp]),
+    ("sur_encoder_backward", [_fp, _EP, _fp, _fp, _i, _fp]),
+    ("sur_flush_encoder_grads", [_fp, _EP]),
+    ("sur_chunk_forward", [_fp, _CP, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _fp, _fp, _fp, _fp]),
+    ("sur_chunk_backward", [_fp, _CP, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _fp, _fp, _fp, _fp]),
+    ("sur_flush_chunk_grads", [_fp, _CP]),
 )
 _lib = None
 
@@ -86,17 +92,39 @@ def _grad_of(p):
 
 
 class _Pack:
-    """Pointers to the weights / gradient accumulators of one module, in the kernel's order."""
+    """Pointers to the weights / gradient tensors of one module in the kernel's order, plus the
+    [rows][sum(size)] partial-gradient buffer the backward kernels accumulate into.  ``dirty`` is set
+    by a backward launch and cleared by ``flush`` (the reduction of the rows into ``param.grad``)."""
 
-    def __init__(self, params, cstruct):
-        self.params, self.c = params, cstruct
+    def __init__(self, params, cstruct, flush_fn, rows):
+        self.params, self.c, self._flush_fn = params, cstruct, flush_fn
+        for i, p in enumerate(params):
+            self.c.size[i] = p.numel()
+        self.psize = sum(p.numel() for p in params)
+        self.partial = None
+        self.dirty = False
+        self.ensure_rows(rows)
         self.refresh()
+
+    def ensure_rows(self, rows):
+        if self.partial is None or self.partial.shape[0] < rows:
+            assert not self.dirty, "cannot grow the partial-gradient buffer with unflushed gradients"
+            self.partial = torch.zeros((rows, self.psize), device=self.params[0].device, dtype=torch.float32)
+            self.c.partial, self.c.rows = self.partial.data_ptr(), rows
 
     def refresh(self):
         for i, p in enumerate(self.params):
             assert p.is_cuda and p.is_contiguous() and p.dtype == torch.float32
             self.c.w[i] = p.data_ptr()
-            self.c.g[i] = _grad_of(p).data_ptr() if p.requires_grad else None
+            self.c.g[i] = _grad_of(p).data_ptr()
+
+    def flush(self):
+        if self.dirty:
+            _check(self._flush_fn(_stream(), ctypes.byref(self.c)))
+            self.dirty = False
+
+
+ENCODER_ROWS = 256  # one partial row per workgroup of the encoder backward (>= #CUs keeps every CU busy)
 
 
 def _encoder_pack(convnet, n):
@@ -118,7 +146,7 @@ def _encoder_pack(convnet, n):
     c.c[:] = chans
     c.stride[:] = strides
     c.n = n
-    return _Pack(params, c)
+    return _Pack(params, c, load().sur_flush_encoder_grads, ENCODER_ROWS)
 
 
 def _dscale_constants(dscaling):
@@ -138,12 +166,12 @@ def _dscale_constants(dscaling):
     raise SurrogateHipError("fused rollout supports dscaling = identity or Normalize(scalar stats).Inverse only")
 
 
-def _step_pack(surrogate):
+def _chunk_pack(surrogate, rows):
     from pdecontrol.surrogates.models.cnn import ConvBlock, DeConvolutionBlock
     from pdecontrol.surrogates.transition import CNNLSTMTransitionModel
     tm = surrogate.transition_model
     if not isinstance(tm, CNNLSTMTransitionModel):
-        raise SurrogateHipError("fused step expects a CNNLSTMTransitionModel")
+        raise SurrogateHipError("fused chunk expects a CNNLSTMTransitionModel")
     cell, dec = tm.cnnlstmcell, surrogate.state_decoder.model
     blocks = [getattr(dec, name) for name in dec.layers]
     ok = (len(blocks) == 4 and isinstance(blocks[0], DeConvolutionBlock) and isinstance(blocks[1], DeConvolutionBlock)
@@ -152,7 +180,7 @@ def _step_pack(surrogate):
           and isinstance(blocks[3].activation, nn.Identity) and blocks[3].layernorm is None
           and all(isinstance(b.activation, nn.SiLU) for b in blocks[:3]))
     if not ok:
-        raise SurrogateHipError("fused step expects the KSAutoRegConvolutionalLSTM decoder layout")
+        raise SurrogateHipError("fused chunk expects the KSAutoRegConvolutionalLSTM decoder layout")
     params = []
     for gate in "ifco":
         wx, wh = getattr(cell, f"Wx{gate}"), getattr(cell, f"Wh{gate}")
@@ -162,43 +190,61 @@ def _step_pack(surrogate):
                d1.deconvolution.weight, d1.deconvolution.bias, d1.layernorm.weight, d1.layernorm.bias,
                c2.convolution.weight, c2.convolution.bias, c2.layernorm.weight, c2.layernorm.bias,
                c3.convolution.weight, c3.convolution.bias]
-    c = StepParams()
+    c = ChunkParams()
     c.ca, c.cs, c.hq = cell.in_channels, cell.out_channels, tm.ssize
     c.c_mid = d1.deconvolution.out_channels
     c.delta = float(surrogate.delta)
     c.mul, c.add = _dscale_constants(surrogate.dscaling)
-    return _Pack(params, c)
+    return _Pack(params, c, load().sur_flush_chunk_grads, rows)
 
 
 class FusedPacks:
-    def __init__(self, surrogate, n):
+    def __init__(self, surrogate, n, batch):
         load()
         self.n = n
         self.state_enc = _encoder_pack(surrogate.state_encoder.model, n)
         self.action_enc = _encoder_pack(surrogate.action_encoder.model, n)
-        self.step = _step_pack(surrogate)
-        dev = self.step.params[0].device
+        self.chunk = _chunk_pack(surrogate, batch)
+        dev = self.chunk.params[0].device
         self.anchor = torch.zeros((), device=dev, requires_grad=True)
         self.key = self._key(surrogate, n)
+        self._flush_queued = False
 
     @staticmethod
     def _key(surrogate, n):
         p = next(surrogate.parameters())
         return (p.data_ptr(), n)
 
-    def refresh(self, surrogate):
-        for pack in (self.state_enc, self.action_enc, self.step):
+    @property
+    def packs(self):
+        return (self.state_enc, self.action_enc, self.chunk)
+
+    def refresh(self, surrogate, batch):
+        self.chunk.ensure_rows(batch)
+        for pack in self.packs:
             pack.refresh()
-        self.step.c.mul, self.step.c.add = _dscale_constants(surrogate.dscaling)
+        self.chunk.c.mul, self.chunk.c.add = _dscale_constants(surrogate.dscaling)
+
+    def flush(self):
+        """Reduce every pending partial-gradient row into param.grad (3 tiny launches at most)."""
+        self._flush_queued = False
+        for pack in self.packs:
+            pack.flush()
+
+    def schedule_flush(self):
+        """Called from inside a backward: run ``flush`` when the current backward pass finishes."""
+        if not self._flush_queued:
+            self._flush_queued = True
+            torch.autograd.Variable._execution_engine.queue_callback(self.flush)
 
 
-def packs_for(surrogate, n):
+def packs_for(surrogate, n, batch):
     packs = getattr(surrogate, "_fused_packs", None)
     if packs is None or packs.key != FusedPacks._key(surrogate, n):
-        packs = FusedPacks(surrogate, n)
+        packs = FusedPacks(surrogate, n, batch)
         object.__setattr__(surrogate, "_fused_packs", packs)
     else:
-        packs.refresh(surrogate)
+        packs.refresh(surrogate, batch)
     return packs
 
 
@@ -207,16 +253,15 @@ def packs_for(surrogate, n):
 # ---------------------------------------------------------------------------------------------
 class _EncoderFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, anchor, pack):
+    def forward(ctx, x, anchor, pack, owner):
         x = x.contiguous()
-        m, n = x.shape[0], pack.c.n
-        h = n
+        m, h = x.shape[0], pack.c.n
         for s in pack.c.stride:
             h //= s
         z = torch.empty((m, pack.c.c[3], h), device=x.device, dtype=torch.float32)
         _check(load().sur_encoder_forward(_stream(), ctypes.byref(pack.c), _p(x), m, _p(z)))
         ctx.save_for_backward(x)
-        ctx.pack, ctx.need_dx = pack, x.requires_grad
+        ctx.pack, ctx.owner, ctx.need_dx = pack, owner, x.requires_grad
         return z
 
     @staticmethod
@@ -225,82 +270,82 @@ class _EncoderFn(torch.autograd.Function):
         dx = torch.empty_like(x) if ctx.need_dx else None
         _check(load().sur_encoder_backward(_stream(), ctypes.byref(ctx.pack.c), _p(x), _p(dz.contiguous()), x.shape[0],
                                            _p(dx)))
-        return dx, None, None
+        ctx.pack.dirty = True
+        ctx.owner.schedule_flush()
+        return dx, None, None, None
 
 
-class _StepFn(torch.autograd.Function):
+class _ChunkFn(torch.autograd.Function):
+    """K rollout steps in one launch; inputs / outputs are time-major (see surrogate_hip.h)."""
+
     @staticmethod
-    def forward(ctx, xlat, h_in, c_prev, base, anchor, pack):
-        xlat, h_in, c_prev, base = xlat.contiguous(), h_in.contiguous(), c_prev.contiguous(), base.contiguous()
-        b = xlat.shape[0]
-        h_out, c_out = torch.empty_like(h_in), torch.empty_like(c_prev)
-        d_out, out = torch.empty_like(base), torch.empty_like(base)
-        _check(load().sur_step_forward(_stream(), ctypes.byref(pack.c), _p(xlat), _p(h_in), _p(c_prev), _p(base), b,
-                                       _p(h_out), _p(c_out), _p(d_out), _p(out)))
-        ctx.save_for_backward(xlat, h_in, c_prev)
-        ctx.pack = pack
-        ctx.needs = (xlat.requires_grad, h_in.requires_grad, c_prev.requires_grad, base.requires_grad)
+    def forward(ctx, xlat_t, lstates_t, states_t, h0, c0, anchor, pack, owner):
+        xlat_t, lstates_t, states_t = xlat_t.contiguous(), lstates_t.contiguous(), states_t.contiguous()
+        h0, c0 = h0.contiguous(), c0.contiguous()
+        k, b = xlat_t.shape[:2]
+        s = lstates_t.shape[0]
+        n = states_t.shape[-1]
+        h_all = torch.empty((k, b, pack.c.cs, pack.c.hq), device=xlat_t.device, dtype=torch.float32)
+        c_all = torch.empty_like(h_all)
+        d_all = torch.empty((k, b, 1, n), device=xlat_t.device, dtype=torch.float32)
+        out_all = torch.empty_like(d_all)
+        _check(load().sur_chunk_forward(_stream(), ctypes.byref(pack.c), _p(xlat_t), _p(lstates_t), _p(states_t), _p(h0),
+                                        _p(c0), k, s, b, _p(h_all), _p(c_all), _p(d_all), _p(out_all)))
+        ctx.save_for_backward(xlat_t, lstates_t, h0, c0, h_all, c_all)
+        ctx.pack, ctx.owner = pack, owner
+        ctx.needs = (xlat_t.requires_grad, lstates_t.requires_grad, h0.requires_grad, c0.requires_grad)
         ctx.set_materialize_grads(False)
-        return h_out, c_out, d_out, out
+        return h_all, c_all, d_all, out_all
 
     @staticmethod
-    def backward(ctx, dh, dc, dd, dout):
-        xlat, h_in, c_prev = ctx.saved_tensors
-        nx, nh, nc, nb = ctx.needs
+    def backward(ctx, dh_all, dc_all, dd_all, dout_all):
+        xlat_t, lstates_t, h0, c0, h_all, c_all = ctx.saved_tensors
+        nx, nl, nh, nc = ctx.needs
         cont = lambda t: None if t is None else t.contiguous()
-        dh, dc, dd, dout = cont(dh), cont(dc), cont(dd), cont(dout)
-        dxlat = torch.empty_like(xlat) if nx else None
-        dh_in = torch.empty_like(h_in) if nh else None
-        dc_prev = torch.empty_like(c_prev) if nc else None
-        dbase = torch.empty_like(dout) if (nb and dout is not None) else None
-        _check(load().sur_step_backward(_stream(), ctypes.byref(ctx.pack.c), _p(xlat), _p(h_in), _p(c_prev), _p(dd),
-                                        _p(dout), _p(dh), _p(dc), xlat.shape[0], _p(dxlat), _p(dh_in), _p(dc_prev),
-                                        _p(dbase)))
-        return dxlat, dh_in, dc_prev, dbase, None, None
+        dh_all, dc_all, dd_all, dout_all = cont(dh_all), cont(dc_all), cont(dd_all), cont(dout_all)
+        dxlat = torch.empty_like(xlat_t) if nx else None
+        dlst = torch.zeros_like(lstates_t) if nl else None
+        dh0 = torch.empty_like(h0) if nh else None
+        dc0 = torch.empty_like(c0) if nc else None
+        k, b = xlat_t.shape[:2]
+        _check(load().sur_chunk_backward(_stream(), ctypes.byref(ctx.pack.c), _p(xlat_t), _p(lstates_t), _p(h0), _p(c0),
+                                         _p(h_all), _p(c_all), _p(dd_all), _p(dout_all), _p(dh_all), _p(dc_all), k,
+                                         lstates_t.shape[0], b, _p(dxlat), _p(dlst), _p(dh0), _p(dc0)))
+        ctx.pack.dirty = True
+        ctx.owner.schedule_flush()
+        return dxlat, dlst, None, dh0, dc0, None, None, None
 
 
-def encode(x, pack, anchor):
+def encode(x, pack, owner):
     """[M, C0, N] -> [M, C3, N/4] through the fused 3-block residual encoder."""
-    return _EncoderFn.apply(x, anchor, pack)
+    return _EncoderFn.apply(x, owner.anchor, pack, owner)
 
 
-def rollout_step(xlat, h_in, c_prev, base, pack, anchor):
-    return _StepFn.apply(xlat, h_in, c_prev, base, anchor, pack)
+def rollout_chunk(xlat_t, lstates_t, states_t, h0, c0, owner):
+    return _ChunkFn.apply(xlat_t, lstates_t, states_t, h0, c0, owner.anchor, owner.chunk, owner)
 
 
 def fused_rollout(surrogate, states, actions, times, targets, hidden):
     """GPU rollout of AutoRegPDESurrogate (same outputs as surrogate.py:79-133; ``inlatents`` is not
-    produced).  states [B,S,1,N], actions [B,A,1,N]."""
+    produced): two encoder launches + ONE launch for all time steps.  states [B,S,1,N], actions [B,A,1,N]."""
     from pdecontrol.mbrl.types import ModelRollout
     from pdecontrol.surrogates.surrogate import action_and_target_indices, take_steps
     b, s_given, _, n = states.shape
-    packs = packs_for(surrogate, n)
-    a_steps = actions.shape[1]
-    hq, cs, ca = packs.step.c.hq, packs.step.c.cs, packs.step.c.ca
-    # time-major so that every per-step slice is contiguous
-    states_t = states.transpose(0, 1).contiguous()                          # [S, B, 1, N]
-    lstates_t = encode(states_t.reshape(s_given * b, 1, n), packs.state_enc, packs.anchor).reshape(s_given, b, cs, hq)
+    owner = packs_for(surrogate, n, b)
+    cs, hq, ca = owner.chunk.c.cs, owner.chunk.c.hq, owner.chunk.c.ca
     aidx, tidx = action_and_target_indices(times, targets, surrogate.delta)
-    actions_t = take_steps(actions, aidx.tolist()).transpose(0, 1).contiguous()   # [K, B, 1, N]
+    # time-major layout: every per-step slice is a contiguous [B, ...] block
+    actions_t = take_steps(actions, aidx.tolist()).transpose(0, 1).contiguous()         # [K, B, 1, N]
     n_steps = actions_t.shape[0]
-    lactions_t = encode(actions_t.reshape(n_steps * b, 1, n), packs.action_enc, packs.anchor).reshape(n_steps, b, ca, hq)
+    s_used = min(s_given, n_steps)
+    states_t = states[:, :s_used].transpose(0, 1).contiguous()                          # [S, B, 1, N]
+    lstates_t = encode(states_t.reshape(s_used * b, 1, n), owner.state_enc, owner).reshape(s_used, b, cs, hq)
+    lactions_t = encode(actions_t.reshape(n_steps * b, 1, n), owner.action_enc, owner).reshape(n_steps, b, ca, hq)
     if hidden is None:
         tm = surrogate.transition_model
-        hidden = (tm.H0.unsqueeze(0).expand(b, -1, -1).contiguous(), tm.C0.unsqueeze(0).expand(b, -1, -1).contiguous())
-    H, C = hidden
-    outs, deltas, latents = [], [], []
-    output = states_t[0]
-    for k in range(n_steps):
-        if k < s_given:
-            h_in, base = lstates_t[k], states_t[k]
-        else:
-            h_in, base = H, output
-        H, C, d, output = rollout_step(lactions_t[k], h_in, C, base, packs.step, packs.anchor)
-        outs.append(output)
-        deltas.append(d)
-        latents.append(H)
+        hidden = (tm.H0.unsqueeze(0).expand(b, -1, -1), tm.C0.unsqueeze(0).expand(b, -1, -1))
+    h_all, c_all, d_all, out_all = rollout_chunk(lactions_t, lstates_t, states_t, hidden[0], hidden[1], owner)
     pick = tidx.tolist()
-    gather = lambda seq, shape: take_steps(torch.stack(seq, dim=1).reshape(shape), pick)
-    return ModelRollout(inlatents=None, outlatents=gather(latents, (b, n_steps, cs, hq)),
-                        deltas=gather(deltas, (b, n_steps, 1, n)), outputs=gather(outs, (b, n_steps, 1, n)),
-                        hidden=(H, C))
+    by_batch = lambda t: take_steps(t.transpose(0, 1), pick)
+    return ModelRollout(inlatents=None, outlatents=by_batch(h_all), deltas=by_batch(d_all), outputs=by_batch(out_all),
+                        hidden=(h_all[-1], c_all[-1]))

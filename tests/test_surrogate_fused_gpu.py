@@ -64,9 +64,9 @@ def test_fused_encoder_forward_backward(dev, which, N):
     ref_g, dx_ref = _grads(m), x.grad.clone()
     _zero(m)
     x.grad = None
-    packs = hipops.packs_for(m.surrogate, N)
+    packs = hipops.packs_for(m.surrogate, N, 7)
     pack = packs.state_enc if which == "state_encoder" else packs.action_enc
-    z = hipops.encode(x, pack, packs.anchor)
+    z = hipops.encode(x, pack, packs)
     _close(z, z_ref, msg="forward")
     z.backward(up)
     _close(x.grad, dx_ref, msg="dx")
@@ -77,37 +77,49 @@ def test_fused_encoder_forward_backward(dev, which, N):
 
 
 @pytest.mark.parametrize("N", [64, 256])
-def test_fused_step_forward_backward(dev, N):
+@pytest.mark.parametrize("K,S", [(1, 1), (4, 2), (3, 1)])
+def test_fused_chunk_forward_backward(dev, N, K, S):
+    """K rollout steps (S teacher forced) in one launch vs the same steps composed from torch modules,
+    with upstream gradients on every output (h_all, c_all, d_all, out_all)."""
     from pdecontrol.surrogates import hipops
     m = _build(dev, N=N)
     sur = m.surrogate
-    hq = N // 4
+    hq, B = N // 4, 5
     g = torch.Generator().manual_seed(7)
     mk = lambda *shape: torch.randn(*shape, generator=g).to(dev).requires_grad_(True)
-    xlat, h_in, c_prev, base = mk(5, 4, hq), mk(5, 16, hq), mk(5, 16, hq), mk(5, 1, N)
-    ups = [torch.randn(5, 16, hq, generator=g).to(dev), torch.randn(5, 16, hq, generator=g).to(dev),
-           torch.randn(5, 1, N, generator=g).to(dev), torch.randn(5, 1, N, generator=g).to(dev)]
+    xlat_t, lstates_t, c0, h0 = mk(K, B, 4, hq), mk(S, B, 16, hq), mk(B, 16, hq), mk(B, 16, hq)
+    states_t = torch.randn(S, B, 1, N, generator=g).to(dev)
+    ups = [torch.randn(K, B, 16, hq, generator=g).to(dev), torch.randn(K, B, 16, hq, generator=g).to(dev),
+           torch.randn(K, B, 1, N, generator=g).to(dev), torch.randn(K, B, 1, N, generator=g).to(dev)]
 
-    def torch_step():
-        H, C = sur.transition_model.cnnlstmcell(xlat, h_in, c_prev)
-        d = sur.state_decoder.model(H)
-        out = base + sur.delta * sur.dscaling(d)
-        return H, C, d, out
+    def torch_chunk():
+        H, C, out = h0, c0, None
+        hs, cs, ds, outs = [], [], [], []
+        for k in range(K):
+            h_in = lstates_t[k] if k < S else H
+            base = states_t[k] if k < S else out
+            H, C = sur.transition_model.cnnlstmcell(xlat_t[k], h_in, C)
+            d = sur.state_decoder.model(H)
+            out = base + sur.delta * sur.dscaling(d)
+            hs.append(H), cs.append(C), ds.append(d), outs.append(out)
+        return torch.stack(hs), torch.stack(cs), torch.stack(ds), torch.stack(outs)
 
-    outs_ref = torch_step()
+    leaves = (xlat_t, lstates_t, c0)
+    outs_ref = torch_chunk()
     torch.autograd.backward(outs_ref, ups)
     ref_g = _grads(m)
-    ref_in = [t.grad.clone() for t in (xlat, h_in, c_prev, base)]
+    ref_in = [t.grad.clone() for t in leaves]
     _zero(m)
-    for t in (xlat, h_in, c_prev, base):
+    for t in leaves + (h0,):
         t.grad = None
-    packs = hipops.packs_for(sur, N)
-    outs = hipops.rollout_step(xlat, h_in, c_prev, base, packs.step, packs.anchor)
-    for name, a, b in zip(("H", "C", "d", "out"), outs, outs_ref):
+    packs = hipops.packs_for(sur, N, B)
+    outs = hipops.rollout_chunk(xlat_t, lstates_t, states_t, h0, c0, packs)
+    for name, a, b in zip(("h_all", "c_all", "d_all", "out_all"), outs, outs_ref):
         _close(a, b, msg=name)
     torch.autograd.backward(outs, ups)
-    for name, t, r in zip(("dxlat", "dh_in", "dc_prev", "dbase"), (xlat, h_in, c_prev, base), ref_in):
+    for name, t, r in zip(("dxlat", "dlstates", "dc0"), leaves, ref_in):
         _close(t.grad, r, msg=name)
+    assert h0.grad is None or float(h0.grad.abs().max()) == 0.0  # S >= 1: h0 never enters the arithmetic
     got = _grads(m)
     for k, v in ref_g.items():
         if k.startswith(("transition_model", "state_decoder")):
