@@ -95,11 +95,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the HIP stepper has no CPU fallback")
+    # one rank per GPU; ranks beyond the visible GPU count share devices (only used to rehearse the
+    # multi-rank code path on a 1-GPU box, with BENCH_DIST_BACKEND=gloo)
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dist = None
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group(backend)
     n_gpus = world if world > 1 else args.gpus
     if world == 1 and args.gpus != 1:
         sys.exit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py ...")
@@ -154,12 +158,19 @@ def main():
     assert int(st_acc.sum()) == 0, "non-finite state during the benchmark"
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
     lay = stepper.layout()
+    traffic = None
+    pmc_file = os.path.join(ROOT, "profiles", "ks_pmc_traffic.json")
+    if os.path.exists(pmc_file):
+        try:
+            traffic = json.load(open(pmc_file)).get(args.workload, {}).get("hbm_bytes_per_launch")
+        except (OSError, ValueError):
+            traffic = None
     total_substeps = n_gpus * E * CFG_STEPS * K
     value = total_substeps / elapsed
     alg_bytes_per_launch = 20.0 * N * E * CFG_STEPS
@@ -186,7 +197,9 @@ def main():
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+            "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+            "traffic_note": "HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                            "command (profiles/ks_pmc_traffic.json; FETCH_SIZE doubled per the gfx950 guide)",
             "kernel": "ks_rk4_fused", "avg_launch_ms": kernel_ms,
             "algorithmic_bytes_per_launch": alg_bytes_per_launch,
             "note": "algorithmic 20*N B per env-sub-step (SURVEY 8d); state stays in VGPRs for all 250 "
