@@ -24,6 +24,24 @@
 
 #include "../../include/surrogate_hip.h"
 
+// Diagnostic build only (-DSUR_STAMP): shader-clock stamps per phase of chunk_fwd for workgroup 0,
+// accumulated in a __device__ buffer nothing else reads (guide section 7, In-kernel stamps).
+#ifdef SUR_STAMP
+__device__ long long sur_stamp_buf[32];
+__device__ long long sur_stamp_last;
+#define STAMP(id)                                                                 \
+    do {                                                                          \
+        __syncthreads();                                                          \
+        if (threadIdx.x == 0 && blockIdx.x == 0) {                                \
+            const long long now_ = (long long)__builtin_amdgcn_s_memtime();       \
+            sur_stamp_buf[id] += now_ - sur_stamp_last;                           \
+            sur_stamp_last = now_;                                                \
+        }                                                                         \
+    } while (0)
+#else
+#define STAMP(id) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int TPB = 256;
@@ -42,114 +60,191 @@ int fail(int code, const char* fmt, ...) {
 __device__ __forceinline__ float sigmoid_(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ __forceinline__ int wrapi(int j, int n) { return j < 0 ? j + n : (j >= n ? j - n : j); }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
-}
 
 // ---------------------------------------------------------------------------------------------
 // block-cooperative layer primitives on LDS-resident activations [C][H] (row-major, H contiguous).
 // Every primitive ends with __syncthreads().
 // ---------------------------------------------------------------------------------------------
 
-// The loops below are latency-bound (dependent LDS read -> FMA chains), not bandwidth-bound, so they are
-// written for instruction-level parallelism: kernel width K is a template parameter (fully unrolled,
-// wrapped indices hoisted out of the channel loop), channel loops are unrolled by 4 with independent
-// accumulators, and layers with fewer outputs than threads split their reduction over SPLIT lanes.
+// ---------------------------------------------------------------------------------------------
+// Every convolution-like layer (forward, data-gradient, weight-gradient; strided circular Conv1d and
+// zero-padded ConvTranspose1d) is a small GEMM  C[M][N] (+)= sum_k A(m,k) * B(k,n)  whose operands are
+// *gathered* from LDS-resident activations / weights through index functors.  The GEMM itself runs
+// on the matrix cores with v_mfma_f32_16x16x4_f32 (exact fp32: bit-for-bit an fmaf chain in k order),
+// one 16x16 output tile per wavefront at a time, so a layer costs ~2 LDS reads + 1 MFMA per 1024
+// MACs instead of ~5 VALU/LDS instructions per 64.  Lane map (guide, section 3): A[l&15][k=l>>4],
+// B[k=l>>4][l&15], result reg i of lane l = C[4*(l>>4)+i][l&15].
+// ---------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// circular Conv1d: out[o][p] (+)= bias[o] + sum_{ci,k} W[o][ci][k] * in[ci][(p*stride + k - pad) mod hin]
-template <int K>
-__device__ void conv_fwd(const float* in, int cin, int hin, const float* W, const float* bias, int cout, int stride,
-                         int pad, float* out, bool accumulate) {
-    const int hout = hin / stride, total = cout * hout;
-    // split the input-channel reduction over `split` adjacent lanes when the layer is small
-    int split = 1;
-    while (split < 8 && total * split * 2 <= (int)blockDim.x && cin % (split * 2) == 0) split *= 2;
-    const int cper = cin / split;
-    for (int base = 0; base < total * split; base += blockDim.x) {
-        const int t = base + threadIdx.x;
-        const bool live = t < total * split;
-        const int idx = live ? t / split : 0, part = t % split;
-        const int o = idx / hout, p = idx - o * hout;
-        int jj[K];
+// Flavour 1 -- reduction over (segment, tap, channel):
+//   C[m][n] = sum_seg sum_{t<T} sum_{c<cin} A_seg[m*a_sm + c*a_sc + t] * B_seg[c*b_sc + col(seg, t, n)]
+// col() returns the gathered column of B for tap t and output column n, or -1 when that tap does not
+// contribute (zero padding / stride parity).  Per tap the channel loop is affine in both operands, so
+// the loads of successive MFMAs are independent of each other (no div/mod/wrap inside the loop).
+struct GemmSeg {
+    const float* a;
+    int a_sm, a_sc;
+    const float* b;
+    int b_sc, cin;
+};
+
+// A subset of the workgroup's wavefronts.  Independent small GEMMs are issued back to back on
+// disjoint wave sets WITHOUT a barrier in between (sync = false) so that they run concurrently; the
+// last one of a group (or an explicit __syncthreads()) closes the phase.
+struct WaveSet {
+    int lo, cnt;
+};
+__device__ __forceinline__ WaveSet all_waves() { return WaveSet{0, (int)(blockDim.x >> 6)}; }
+__device__ __forceinline__ WaveSet lower_half() { const int nw = blockDim.x >> 6; return WaveSet{0, nw > 1 ? nw / 2 : 1}; }
+__device__ __forceinline__ WaveSet upper_half() {
+    const int nw = blockDim.x >> 6;
+    return nw > 1 ? WaveSet{nw / 2, nw - nw / 2} : WaveSet{0, 1};
+}
+
+template <int T, int NSEG, class ColFn, class PutFn>
+__device__ __forceinline__ void gemm_taps(WaveSet ws, bool sync, int M, int N, const GemmSeg (&seg)[NSEG], ColFn col,
+                                          PutFn put) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (wid >= ws.lo && wid < ws.lo + ws.cnt) {
+        const int nwg = blockDim.x >> 6;
+        const int wave = wid - ws.lo, nw = ws.cnt < nwg ? ws.cnt : nwg;
+        const int r = lane & 15, q = lane >> 4;
+        const int tn_count = (N + 15) >> 4, tiles = ((M + 15) >> 4) * tn_count;
+        for (int t = wave; t < tiles; t += nw) {
+            const int m0 = (t / tn_count) << 4, n0 = (t % tn_count) << 4;
+            const int m = m0 + r, n = n0 + r;
+            const bool m_ok = m < M;
+            const int m_safe = m_ok ? m : M - 1;
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < K; ++k) jj[k] = wrapi(p * stride + k - pad, hin);
-        const float* w = W + ((size_t)o * cin + part * cper) * K;
-        const float* row = in + (part * cper) * hin;
-        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
-        int ci = 0;
-        for (; ci + 4 <= cper; ci += 4) {
+            for (int sg = 0; sg < NSEG; ++sg) {
+                const GemmSeg& S = seg[sg];
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                a0 = fmaf(w[(ci + 0) * K + k], row[(ci + 0) * hin + jj[k]], a0);
-                a1 = fmaf(w[(ci + 1) * K + k], row[(ci + 1) * hin + jj[k]], a1);
-                a2 = fmaf(w[(ci + 2) * K + k], row[(ci + 2) * hin + jj[k]], a2);
-                a3 = fmaf(w[(ci + 3) * K + k], row[(ci + 3) * hin + jj[k]], a3);
+                for (int tap = 0; tap < T; ++tap) {
+                    const int cidx = (n < N) ? col(sg, tap, n) : -1;
+                    const float* ap = S.a + m_safe * S.a_sm + tap;
+                    const float* bp = S.b + (cidx >= 0 ? cidx : 0);
+                    const bool b_ok = cidx >= 0;
+                    int c0 = 0;
+                    for (; c0 + 8 <= S.cin; c0 += 8) {  // 2 MFMAs per trip on independent accumulators
+                        const float a0 = ap[(c0 + q) * S.a_sc], b0 = bp[(c0 + q) * S.b_sc];
+                        const float a1 = ap[(c0 + 4 + q) * S.a_sc], b1 = bp[(c0 + 4 + q) * S.b_sc];
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(m_ok ? a0 : 0.f, b_ok ? b0 : 0.f, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(m_ok ? a1 : 0.f, b_ok ? b1 : 0.f, acc1, 0, 0, 0);
+                    }
+                    for (; c0 < S.cin; c0 += 4) {
+                        const int c = c0 + q;
+                        const bool c_ok = c < S.cin;
+                        const int cs_ = c_ok ? c : S.cin - 1;
+                        const float a0 = ap[cs_ * S.a_sc], b0 = bp[cs_ * S.b_sc];
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32((m_ok && c_ok) ? a0 : 0.f, (b_ok && c_ok) ? b0 : 0.f, acc0,
+                                                                    0, 0, 0);
+                    }
+                }
             }
-        }
-        for (; ci < cper; ++ci) {
 #pragma unroll
-            for (int k = 0; k < K; ++k) a0 = fmaf(w[ci * K + k], row[ci * hin + jj[k]], a0);
-        }
-        float acc = (a0 + a1) + (a2 + a3);
-        for (int m = 1; m < split; m <<= 1) acc += __shfl_xor(acc, m, 64);
-        if (live && part == 0) {
-            if (bias) acc += bias[o];
-            out[idx] = accumulate ? out[idx] + acc : acc;
+            for (int i = 0; i < 4; ++i) put(m0 + q * 4 + i, n0 + r, acc0[i] + acc1[i]);
         }
     }
-    __syncthreads();
+    if (sync) __syncthreads();
+}
+
+// Flavour 2 -- reduction over positions p (P a multiple of 4):
+//   C[m][n] = sum_p A[m*a_sm + p] * b_at(state(n), p);   state(n) decodes the output column once.
+template <class PrepFn, class FetchFn, class PutFn>
+__device__ __forceinline__ void gemm_pos(WaveSet ws, bool sync, int M, int N, int P, const float* a, int a_sm,
+                                         PrepFn prep, FetchFn fetch, PutFn put) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (wid >= ws.lo && wid < ws.lo + ws.cnt) {
+        const int nwg = blockDim.x >> 6;
+        const int wave = wid - ws.lo, nw = ws.cnt < nwg ? ws.cnt : nwg;
+        const int r = lane & 15, q = lane >> 4;
+        const int tn_count = (N + 15) >> 4, tiles = ((M + 15) >> 4) * tn_count;
+        for (int t = wave; t < tiles; t += nw) {
+            const int m0 = (t / tn_count) << 4, n0 = (t % tn_count) << 4;
+            const int m = m0 + r, n = n0 + r;
+            const bool m_ok = m < M, n_ok = n < N;
+            const float* ap = a + (m_ok ? m : M - 1) * a_sm;
+            const auto st = prep(n_ok ? n : N - 1);
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            int p = 0;
+            for (; p + 8 <= P; p += 8) {
+                const float a0 = ap[p + q], b0 = fetch(st, p + q);
+                const float a1 = ap[p + 4 + q], b1 = fetch(st, p + 4 + q);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(m_ok ? a0 : 0.f, n_ok ? b0 : 0.f, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(m_ok ? a1 : 0.f, n_ok ? b1 : 0.f, acc1, 0, 0, 0);
+            }
+            for (; p < P; p += 4) {
+                const float a0 = ap[p + q], b0 = fetch(st, p + q);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(m_ok ? a0 : 0.f, n_ok ? b0 : 0.f, acc0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) put(m0 + q * 4 + i, n0 + r, acc0[i] + acc1[i]);
+        }
+    }
+    if (sync) __syncthreads();
+}
+
+// circular Conv1d forward: out[o][p] (+)= bias[o] + sum_{ci,k} W[o][ci][k] * in[ci][(p*stride + k - pad) mod hin]
+template <int K>
+__device__ void conv_fwd(const float* in, int cin, int hin, const float* W, const float* bias, int cout, int stride,
+                         int pad, float* out, bool accumulate, WaveSet ws = WaveSet{0, 1 << 20}, bool sync = true) {
+    const int hout = hin / stride;
+    if (cout == 1) {  // a single output row would waste 15/16 of an MFMA tile: split-lane VALU reduction
+        const int total = hout;
+        int split = 1;
+        while (split < 8 && total * split * 2 <= (int)blockDim.x && cin % (split * 2) == 0) split *= 2;
+        const int cper = cin / split;
+        for (int base = 0; base < total * split; base += blockDim.x) {
+            const int t = base + threadIdx.x;
+            const bool live = t < total * split;
+            const int p = live ? t / split : 0, part = t % split;
+            float acc = 0.0f;
+            for (int ci = part * cper; ci < (part + 1) * cper; ++ci) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) acc = fmaf(W[ci * K + k], in[ci * hin + wrapi(p * stride + k - pad, hin)], acc);
+            }
+            for (int m = 1; m < split; m <<= 1) acc += __shfl_xor(acc, m, 64);
+            if (live && part == 0) {
+                if (bias) acc += bias[0];
+                out[p] = accumulate ? out[p] + acc : acc;
+            }
+        }
+        if (sync) __syncthreads();
+        return;
+    }
+    const GemmSeg seg[1] = {{W, cin * K, K, in, hin, cin}};
+    gemm_taps<K, 1>(ws, sync, cout, hout, seg, [&](int, int tap, int n) { return wrapi(n * stride + tap - pad, hin); },
+                    [&](int m, int n, float v) {
+                        if (m < cout) {
+                            if (bias) v += bias[m];
+                            out[m * hout + n] = accumulate ? out[m * hout + n] + v : v;
+                        }
+                    });
 }
 
 // din[ci][j] (+)= sum_{o,k : (p*stride + k - pad) mod hin == j} W[o][ci][k] * dout[o][p]
 template <int K>
 __device__ void conv_bwd_data(const float* dout, int cout, int hin, const float* W, int cin, int stride, int pad,
-                              float* din, bool accumulate) {
+                              float* din, bool accumulate, WaveSet ws = WaveSet{0, 1 << 20}, bool sync = true) {
     const int hout = hin / stride;
-    for (int idx = threadIdx.x; idx < cin * hin; idx += blockDim.x) {
-        const int ci = idx / hin, j = idx - ci * hin;
-        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const int t = wrapi(j - k + pad, hin);
-            if (t % stride) continue;
-            const int p = t / stride;
-            const float* w = W + (size_t)ci * K + k;
-            const float* d = dout + p;
-            int o = 0;
-            for (; o + 4 <= cout; o += 4) {
-                a0 = fmaf(w[(size_t)(o + 0) * cin * K], d[(o + 0) * hout], a0);
-                a1 = fmaf(w[(size_t)(o + 1) * cin * K], d[(o + 1) * hout], a1);
-                a2 = fmaf(w[(size_t)(o + 2) * cin * K], d[(o + 2) * hout], a2);
-                a3 = fmaf(w[(size_t)(o + 3) * cin * K], d[(o + 3) * hout], a3);
-            }
-            for (; o < cout; ++o) a0 = fmaf(w[(size_t)o * cin * K], d[o * hout], a0);
-        }
-        const float acc = (a0 + a1) + (a2 + a3);
-        din[idx] = accumulate ? din[idx] + acc : acc;
-    }
-    __syncthreads();
+    const GemmSeg seg[1] = {{W, K, cin * K, dout, hout, cout}};  // A[m=ci][c=o][tap] = W[(o*cin + ci)*K + tap]
+    gemm_taps<K, 1>(ws, sync, cin, hin, seg,
+                    [&](int, int tap, int j) {
+                        const int t = wrapi(j - tap + pad, hin);
+                        return (t % stride) ? -1 : t / stride;
+                    },
+                    [&](int m, int j, float v) {
+                        if (m < cin) din[m * hin + j] = accumulate ? din[m * hin + j] + v : v;
+                    });
 }
 
 // gW[o][ci][k] += sum_p dout[o][p] * in[ci][(p*stride + k - pad) mod hin];  gb[o] += sum_p dout[o][p]
 template <int K>
 __device__ void conv_bwd_weight(const float* dout, int cout, const float* in, int cin, int hin, int stride, int pad,
-                                float* gW, float* gb) {
-    const int hout = hin / stride;
-    for (int idx = threadIdx.x; idx < cout * cin * K; idx += blockDim.x) {
-        const int o = idx / (cin * K), r = idx - o * cin * K, ci = r / K, k = r - ci * K;
-        const float* d = dout + o * hout;
-        const float* row = in + ci * hin;
-        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
-        for (int p = 0; p < hout; p += 4) {  // hout is a multiple of 4 for every layer of this model family
-            a0 = fmaf(d[p + 0], row[wrapi((p + 0) * stride + k - pad, hin)], a0);
-            a1 = fmaf(d[p + 1], row[wrapi((p + 1) * stride + k - pad, hin)], a1);
-            a2 = fmaf(d[p + 2], row[wrapi((p + 2) * stride + k - pad, hin)], a2);
-            a3 = fmaf(d[p + 3], row[wrapi((p + 3) * stride + k - pad, hin)], a3);
-        }
-        gW[idx] += (a0 + a1) + (a2 + a3);
-    }
+                                float* gW, float* gb, WaveSet ws = WaveSet{0, 1 << 20}, bool sync = true) {
+    const int hout = hin / stride, ncols = cin * K;
     if (gb) {
         for (int o = threadIdx.x; o < cout; o += blockDim.x) {
             float a0 = 0.0f, a1 = 0.0f;
@@ -160,81 +255,67 @@ __device__ void conv_bwd_weight(const float* dout, int cout, const float* in, in
             gb[o] += a0 + a1;
         }
     }
-    __syncthreads();
+    if (cout == 1) {
+        for (int idx = threadIdx.x; idx < ncols; idx += blockDim.x) {
+            const int ci = idx / K, k = idx - ci * K;
+            const float* row = in + ci * hin;
+            float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+            for (int p = 0; p < hout; p += 4) {
+                a0 = fmaf(dout[p + 0], row[wrapi((p + 0) * stride + k - pad, hin)], a0);
+                a1 = fmaf(dout[p + 1], row[wrapi((p + 1) * stride + k - pad, hin)], a1);
+                a2 = fmaf(dout[p + 2], row[wrapi((p + 2) * stride + k - pad, hin)], a2);
+                a3 = fmaf(dout[p + 3], row[wrapi((p + 3) * stride + k - pad, hin)], a3);
+            }
+            gW[idx] += (a0 + a1) + (a2 + a3);
+        }
+        if (sync) __syncthreads();
+        return;
+    }
+    struct St { const float* row; int off; };
+    gemm_pos(ws, sync, cout, ncols, hout, dout, hout,
+             [&](int n) {
+                 const int ci = n / K, k = n - ci * K;
+                 return St{in + ci * hin, k - pad};
+             },
+             [&](const St& st, int p) { return st.row[wrapi(p * stride + st.off, hin)]; },
+             [&](int m, int n, float v) {
+                 if (m < cout && n < ncols) gW[m * ncols + n] += v;
+             });
 }
 
 // ConvTranspose1d(k=3, stride=2, padding=1, output_padding=1), zero padded; W[ci][o][k]; hout = 2*hin
 // out[o][j] = b[o] + sum_{ci,k : j = 2i - 1 + k} W[ci][o][k] * in[ci][i]
 __device__ void deconv_fwd(const float* in, int cin, int hin, const float* W, const float* bias, int cout,
-                           float* out) {
+                           float* out, WaveSet ws = WaveSet{0, 1 << 20}, bool sync = true) {
     const int hout = 2 * hin;
-    for (int idx = threadIdx.x; idx < cout * hout; idx += blockDim.x) {
-        const int o = idx / hout, j = idx - o * hout;
-        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int t = j + 1 - k;
-            if (t < 0 || (t & 1)) continue;
-            const int i = t >> 1;
-            if (i >= hin) continue;
-            const float* w = W + (size_t)o * 3 + k;
-            const float* x = in + i;
-            int ci = 0;
-            for (; ci + 4 <= cin; ci += 4) {
-                a0 = fmaf(w[(size_t)(ci + 0) * cout * 3], x[(ci + 0) * hin], a0);
-                a1 = fmaf(w[(size_t)(ci + 1) * cout * 3], x[(ci + 1) * hin], a1);
-                a2 = fmaf(w[(size_t)(ci + 2) * cout * 3], x[(ci + 2) * hin], a2);
-                a3 = fmaf(w[(size_t)(ci + 3) * cout * 3], x[(ci + 3) * hin], a3);
-            }
-            for (; ci < cin; ++ci) a0 = fmaf(w[(size_t)ci * cout * 3], x[ci * hin], a0);
-        }
-        out[idx] = bias[o] + ((a0 + a1) + (a2 + a3));
-    }
-    __syncthreads();
+    const GemmSeg seg[1] = {{W, 3, cout * 3, in, hin, cin}};  // A[m=o][c=ci][tap] = W[(ci*cout + o)*3 + tap]
+    gemm_taps<3, 1>(ws, sync, cout, hout, seg,
+                    [&](int, int tap, int j) {
+                        const int t = j + 1 - tap;
+                        return (t < 0 || (t & 1) || (t >> 1) >= hin) ? -1 : (t >> 1);
+                    },
+                    [&](int m, int j, float v) {
+                        if (m < cout) out[m * hout + j] = v + bias[m];
+                    });
 }
 
-__device__ void deconv_bwd_data(const float* dout, int cout, int hin, const float* W, int cin, float* din) {
+__device__ void deconv_bwd_data(const float* dout, int cout, int hin, const float* W, int cin, float* din,
+                                WaveSet ws = WaveSet{0, 1 << 20}, bool sync = true) {
     const int hout = 2 * hin;
-    for (int idx = threadIdx.x; idx < cin * hin; idx += blockDim.x) {
-        const int ci = idx / hin, i = idx - ci * hin;
-        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int j = 2 * i - 1 + k;
-            if (j < 0 || j >= hout) continue;
-            const float* w = W + (size_t)ci * cout * 3 + k;
-            const float* d = dout + j;
-            int o = 0;
-            for (; o + 4 <= cout; o += 4) {
-                a0 = fmaf(w[(o + 0) * 3], d[(o + 0) * hout], a0);
-                a1 = fmaf(w[(o + 1) * 3], d[(o + 1) * hout], a1);
-                a2 = fmaf(w[(o + 2) * 3], d[(o + 2) * hout], a2);
-                a3 = fmaf(w[(o + 3) * 3], d[(o + 3) * hout], a3);
-            }
-            for (; o < cout; ++o) a0 = fmaf(w[o * 3], d[o * hout], a0);
-        }
-        din[idx] = (a0 + a1) + (a2 + a3);
-    }
-    __syncthreads();
+    const GemmSeg seg[1] = {{W, cout * 3, 3, dout, hout, cout}};  // A[m=ci][c=o][tap] = W[(ci*cout + o)*3 + tap]
+    gemm_taps<3, 1>(ws, sync, cin, hin, seg,
+                    [&](int, int tap, int i) {
+                        const int j = 2 * i - 1 + tap;
+                        return (j < 0 || j >= hout) ? -1 : j;
+                    },
+                    [&](int m, int i, float v) {
+                        if (m < cin) din[m * hin + i] = v;
+                    });
 }
 
-__device__ void deconv_bwd_weight(const float* dout, int cout, const float* in, int cin, int hin, float* gW, float* gb) {
-    const int hout = 2 * hin;
-    for (int idx = threadIdx.x; idx < cin * cout * 3; idx += blockDim.x) {
-        const int ci = idx / (cout * 3), r = idx - ci * cout * 3, o = r / 3, k = r - o * 3;
-        const float* x = in + ci * hin;
-        const float* d = dout + o * hout + (k - 1);  // j = 2i - 1 + k
-        float a0 = 0.0f, a1 = 0.0f;
-        // i = 0 (k = 0) and i = hin-1 (k = 2 -> j = hout) fall outside the output: handle the ends explicitly
-        const int i_lo = (k == 0) ? 1 : 0, i_hi = hin;  // j = 2i + k - 1 < hout always holds for k <= 2, i < hin
-        int i = i_lo;
-        for (; i + 2 <= i_hi; i += 2) {
-            a0 = fmaf(x[i], d[2 * i], a0);
-            a1 = fmaf(x[i + 1], d[2 * i + 2], a1);
-        }
-        for (; i < i_hi; ++i) a0 = fmaf(x[i], d[2 * i], a0);
-        gW[idx] += a0 + a1;
-    }
+__device__ void deconv_bwd_weight(const float* dout, int cout, const float* in, int cin, int hin, float* gW, float* gb,
+                                  WaveSet ws = WaveSet{0, 1 << 20}, bool sync = true) {
+    const int hout = 2 * hin, ncols = cout * 3;
     for (int o = threadIdx.x; o < cout; o += blockDim.x) {
         float a0 = 0.0f, a1 = 0.0f;
         for (int j = 0; j < hout; j += 2) {
@@ -243,89 +324,168 @@ __device__ void deconv_bwd_weight(const float* dout, int cout, const float* in, 
         }
         gb[o] += a0 + a1;
     }
-    __syncthreads();
+    struct St { const float* row; int off; };
+    gemm_pos(ws, sync, cin, ncols, hin, in, hin,
+             [&](int n) {
+                 const int o = n / 3, k = n - o * 3;
+                 return St{dout + o * hout, k - 1};
+             },
+             [&](const St& st, int i) {
+                 const int j = 2 * i + st.off;
+                 return (j < 0 || j >= hout) ? 0.0f : st.row[j];
+             },
+             [&](int m, int n, float v) {
+                 if (m < cin && n < ncols) gW[m * ncols + n] += v;
+             });
 }
 
-// out = LayerNorm_H(act(pre)) * gamma[p] + beta[p], act = SiLU or identity; one wave per channel
-__device__ void act_ln_fwd(const float* pre, int C, int H, const float* gamma,
-                           const float* beta, bool silu, float* out) {
+// ---------------------------------------------------------------------------------------------
+// LayerNorm over the spatial axis fused with the preceding activation.  A channel is handled by a
+// group of LPC = min(64, H) lanes (64/LPC channels per wavefront at a time), each lane keeping its
+// H/LPC activated values in registers; mean and E[y^2] are reduced TOGETHER (two interleaved chains)
+// with DPP row rotations inside 16-lane rows and one ds_bpermute per doubling beyond a row.
+// ---------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_rot(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+
+// sums of a and b over aligned groups of `lpc` lanes (16, 32 or 64); every lane gets both totals
+__device__ __forceinline__ void group_sum2(float& a, float& b, int lpc) {
+    a += dpp_rot<0x128>(a);  // row_ror:8
+    b += dpp_rot<0x128>(b);
+    a += dpp_rot<0x124>(a);  // row_ror:4
+    b += dpp_rot<0x124>(b);
+    a += dpp_rot<0x122>(a);  // row_ror:2
+    b += dpp_rot<0x122>(b);
+    a += dpp_rot<0x121>(a);  // row_ror:1
+    b += dpp_rot<0x121>(b);
+    if (lpc >= 32) {
+        a += __shfl_xor(a, 16, 64);
+        b += __shfl_xor(b, 16, 64);
+    }
+    if (lpc >= 64) {
+        a += __shfl_xor(a, 32, 64);
+        b += __shfl_xor(b, 32, 64);
+    }
+}
+
+constexpr int LN_MAX_EPL = 4;  // H <= 256
+
+// out = LayerNorm_H(act(pre)) * gamma[p] + beta[p], act = SiLU or identity
+__device__ void act_ln_fwd(const float* pre, int C, int H, const float* gamma, const float* beta, bool silu,
+                           float* out) {
+    const int lpc = H < 64 ? H : 64, gpw = 64 / lpc, epl = H / lpc;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    for (int c = wave; c < C; c += nw) {
-        const float* x = pre + c * H;
-        float s = 0.0f;
-        for (int p = lane; p < H; p += 64) {
-            const float v = x[p];
-            s += silu ? v * sigmoid_(v) : v;
+    const int grp = lane / lpc, gl = lane - grp * lpc;
+    const float inv_h = 1.0f / H;
+    for (int c0 = 0; c0 < C; c0 += nw * gpw) {
+        const int c = c0 + wave * gpw + grp;
+        const bool live = c < C;
+        const float* x = pre + (live ? c : 0) * H;
+        float y[LN_MAX_EPL];
+        float s = 0.0f, ss = 0.0f;
+#pragma unroll
+        for (int e = 0; e < LN_MAX_EPL; ++e) {
+            if (e < epl) {
+                const float v = x[gl + e * lpc];
+                y[e] = silu ? v * sigmoid_(v) : v;
+                s += y[e];
+                ss = fmaf(y[e], y[e], ss);
+            }
         }
-        const float mean = wave_sum(s) / H;
-        float ss = 0.0f;
-        for (int p = lane; p < H; p += 64) {
-            const float v = x[p];
-            const float y = (silu ? v * sigmoid_(v) : v) - mean;
-            ss = fmaf(y, y, ss);
-        }
-        const float rstd = rsqrtf(wave_sum(ss) / H + LN_EPS);
-        for (int p = lane; p < H; p += 64) {
-            const float v = x[p];
-            const float y = silu ? v * sigmoid_(v) : v;
-            out[c * H + p] = fmaf((y - mean) * rstd, gamma[p], beta[p]);
+        group_sum2(s, ss, lpc);
+        const float mean = s * inv_h;
+        const float var = fmaxf(fmaf(-mean, mean, ss * inv_h), 0.0f);
+        const float rstd = rsqrtf(var + LN_EPS);
+        if (live) {
+#pragma unroll
+            for (int e = 0; e < LN_MAX_EPL; ++e) {
+                if (e < epl) {
+                    const int p = gl + e * lpc;
+                    out[c * H + p] = fmaf((y[e] - mean) * rstd, gamma[p], beta[p]);
+                }
+            }
         }
     }
     __syncthreads();
 }
 
 // backward of act_ln_fwd: dpre from dout; accumulates ggamma / gbeta.  xhat_scratch: [C][H] work space.
-__device__ void act_ln_bwd(const float* dout, const float* pre, int C, int H, const float* gamma,
-                           bool silu, float* dpre, float* xhat_scratch, float* ggamma, float* gbeta) {
+__device__ void act_ln_bwd(const float* dout, const float* pre, int C, int H, const float* gamma, bool silu,
+                           float* dpre, float* xhat_scratch, float* ggamma, float* gbeta) {
+    const int lpc = H < 64 ? H : 64, gpw = 64 / lpc, epl = H / lpc;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    for (int c = wave; c < C; c += nw) {
-        const float* x = pre + c * H;
-        float s = 0.0f;
-        for (int p = lane; p < H; p += 64) {
-            const float v = x[p];
-            s += silu ? v * sigmoid_(v) : v;
-        }
-        const float mean = wave_sum(s) / H;
-        float ss = 0.0f;
-        for (int p = lane; p < H; p += 64) {
-            const float v = x[p];
-            const float y = (silu ? v * sigmoid_(v) : v) - mean;
-            ss = fmaf(y, y, ss);
-        }
-        const float rstd = rsqrtf(wave_sum(ss) / H + LN_EPS);
-        float m1 = 0.0f, m2 = 0.0f;
-        for (int p = lane; p < H; p += 64) {
-            const float v = x[p];
-            const float xh = ((silu ? v * sigmoid_(v) : v) - mean) * rstd;
-            const float dxh = dout[c * H + p] * gamma[p];
-            xhat_scratch[c * H + p] = xh;
-            m1 += dxh;
-            m2 = fmaf(dxh, xh, m2);
-        }
-        m1 = wave_sum(m1) / H;
-        m2 = wave_sum(m2) / H;
-        for (int p = lane; p < H; p += 64) {
-            const float v = x[p];
-            const float xh = xhat_scratch[c * H + p];
-            const float dxh = dout[c * H + p] * gamma[p];
-            float dy = rstd * (dxh - m1 - xh * m2);
-            if (silu) {
-                const float sg = sigmoid_(v);
-                dy *= sg * (1.0f + v * (1.0f - sg));
+    const int grp = lane / lpc, gl = lane - grp * lpc;
+    const float inv_h = 1.0f / H;
+    for (int c0 = 0; c0 < C; c0 += nw * gpw) {
+        const int c = c0 + wave * gpw + grp;
+        const bool live = c < C;
+        const int cc = live ? c : 0;
+        const float* x = pre + cc * H;
+        float y[LN_MAX_EPL], v_[LN_MAX_EPL], dxh[LN_MAX_EPL];
+        float s = 0.0f, ss = 0.0f;
+#pragma unroll
+        for (int e = 0; e < LN_MAX_EPL; ++e) {
+            if (e < epl) {
+                const int p = gl + e * lpc;
+                v_[e] = x[p];
+                y[e] = silu ? v_[e] * sigmoid_(v_[e]) : v_[e];
+                dxh[e] = dout[cc * H + p] * gamma[p];
+                s += y[e];
+                ss = fmaf(y[e], y[e], ss);
             }
-            dpre[c * H + p] = dy;
+        }
+        group_sum2(s, ss, lpc);
+        const float mean = s * inv_h;
+        const float var = fmaxf(fmaf(-mean, mean, ss * inv_h), 0.0f);
+        const float rstd = rsqrtf(var + LN_EPS);
+        float m1 = 0.0f, m2 = 0.0f;
+#pragma unroll
+        for (int e = 0; e < LN_MAX_EPL; ++e) {
+            if (e < epl) {
+                y[e] = (y[e] - mean) * rstd;  // xhat
+                m1 += dxh[e];
+                m2 = fmaf(dxh[e], y[e], m2);
+            }
+        }
+        group_sum2(m1, m2, lpc);
+        m1 *= inv_h;
+        m2 *= inv_h;
+        if (live) {
+#pragma unroll
+            for (int e = 0; e < LN_MAX_EPL; ++e) {
+                if (e < epl) {
+                    const int p = gl + e * lpc;
+                    float dy = rstd * (dxh[e] - m1 - y[e] * m2);
+                    if (silu) {
+                        const float sg = sigmoid_(v_[e]);
+                        dy *= sg * (1.0f + v_[e] * (1.0f - sg));
+                    }
+                    xhat_scratch[c * H + p] = y[e];
+                    dpre[c * H + p] = dy;
+                }
+            }
         }
     }
     __syncthreads();
     for (int p = threadIdx.x; p < H; p += blockDim.x) {
-        float gg = 0.0f, gb = 0.0f;
-        for (int c = 0; c < C; ++c) {
-            const float d = dout[c * H + p];
-            gg = fmaf(d, xhat_scratch[c * H + p], gg);
-            gb += d;
+        float gg0 = 0.0f, gg1 = 0.0f, gb0 = 0.0f, gb1 = 0.0f;
+        int c = 0;
+        for (; c + 2 <= C; c += 2) {
+            const float d0 = dout[c * H + p], d1 = dout[(c + 1) * H + p];
+            gg0 = fmaf(d0, xhat_scratch[c * H + p], gg0);
+            gg1 = fmaf(d1, xhat_scratch[(c + 1) * H + p], gg1);
+            gb0 += d0;
+            gb1 += d1;
         }
-        ggamma[p] += gg;
-        gbeta[p] += gb;
+        for (; c < C; ++c) {
+            const float d0 = dout[c * H + p];
+            gg0 = fmaf(d0, xhat_scratch[c * H + p], gg0);
+            gb0 += d0;
+        }
+        ggamma[p] += gg0 + gg1;
+        gbeta[p] += gb0 + gb1;
     }
     __syncthreads();
 }
@@ -393,8 +553,8 @@ struct RBBuf {  // LDS pointers of one block's forward intermediates
 };
 
 __device__ void rb_forward(const RBBuf& b, const float* const* w) {
-    conv_fwd<1>(b.in, b.cin, b.hin, w[SUR_RB_SKIP], nullptr, b.cout, b.stride, 0, b.skip, false);
-    conv_fwd<3>(b.in, b.cin, b.hin, w[SUR_RB_CONV1], nullptr, b.cout, b.stride, 1, b.a1pre, false);
+    conv_fwd<1>(b.in, b.cin, b.hin, w[SUR_RB_SKIP], nullptr, b.cout, b.stride, 0, b.skip, false, lower_half(), false);
+    conv_fwd<3>(b.in, b.cin, b.hin, w[SUR_RB_CONV1], nullptr, b.cout, b.stride, 1, b.a1pre, false, upper_half(), true);
     act_ln_fwd(b.a1pre, b.cout, b.hout, w[SUR_RB_LN1_W], w[SUR_RB_LN1_B], true, b.a1);
     conv_fwd<3>(b.a1, b.cout, b.hout, w[SUR_RB_CONV2], nullptr, b.cout, 1, 1, b.a2pre, false);
     act_ln_fwd(b.a2pre, b.cout, b.hout, w[SUR_RB_LN2_W], w[SUR_RB_LN2_B], true, b.a2);
@@ -409,15 +569,15 @@ __device__ void rb_backward(const RBBuf& b, const float* const* w, float* const*
                             float* g1, float* g2, float* g3, float* xh) {
     act_ln_bwd(dout, b.s, b.cout, b.hout, w[SUR_RB_LN3_W], false, g1, xh, g[SUR_RB_LN3_W], g[SUR_RB_LN3_B]);
     // skip path
-    conv_bwd_weight<1>(g1, b.cout, b.in, b.cin, b.hin, b.stride, 0, g[SUR_RB_SKIP], nullptr);
-    conv_bwd_data<1>(g1, b.cout, b.hin, w[SUR_RB_SKIP], b.cin, b.stride, 0, din, false);
+    conv_bwd_weight<1>(g1, b.cout, b.in, b.cin, b.hin, b.stride, 0, g[SUR_RB_SKIP], nullptr, lower_half(), false);
+    conv_bwd_data<1>(g1, b.cout, b.hin, w[SUR_RB_SKIP], b.cin, b.stride, 0, din, false, upper_half(), true);
     // residual path
     act_ln_bwd(g1, b.a2pre, b.cout, b.hout, w[SUR_RB_LN2_W], true, g2, xh, g[SUR_RB_LN2_W], g[SUR_RB_LN2_B]);
-    conv_bwd_weight<3>(g2, b.cout, b.a1, b.cout, b.hout, 1, 1, g[SUR_RB_CONV2], nullptr);
-    conv_bwd_data<3>(g2, b.cout, b.hout, w[SUR_RB_CONV2], b.cout, 1, 1, g3, false);
+    conv_bwd_weight<3>(g2, b.cout, b.a1, b.cout, b.hout, 1, 1, g[SUR_RB_CONV2], nullptr, lower_half(), false);
+    conv_bwd_data<3>(g2, b.cout, b.hout, w[SUR_RB_CONV2], b.cout, 1, 1, g3, false, upper_half(), true);
     act_ln_bwd(g3, b.a1pre, b.cout, b.hout, w[SUR_RB_LN1_W], true, g1, xh, g[SUR_RB_LN1_W], g[SUR_RB_LN1_B]);
-    conv_bwd_weight<3>(g1, b.cout, b.in, b.cin, b.hin, b.stride, 1, g[SUR_RB_CONV1], nullptr);
-    conv_bwd_data<3>(g1, b.cout, b.hin, w[SUR_RB_CONV1], b.cin, b.stride, 1, din, true);
+    conv_bwd_weight<3>(g1, b.cout, b.in, b.cin, b.hin, b.stride, 1, g[SUR_RB_CONV1], nullptr, lower_half(), false);
+    conv_bwd_data<3>(g1, b.cout, b.hin, w[SUR_RB_CONV1], b.cin, b.stride, 1, din, true, upper_half(), true);
 }
 
 struct EncLayout {
@@ -594,11 +754,32 @@ __device__ void step_layout(const sur_chunk_params& p, float* lds, bool backward
 // one rollout step on LDS-resident x, h, c: fills gates (activated), cnew, hnew, decoder activations, d
 __device__ void step_forward_body(const sur_chunk_params& p, const StepLayout& L, const float* const* w) {
     const int s = p.cs * p.hq;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        conv_fwd<3>(L.x, p.ca, p.hq, w[SUR_ST_WXI + 3 * g], w[SUR_ST_BXI + 3 * g], p.cs, 1, 1, L.gates + g * s, false);
-        conv_fwd<3>(L.h, p.cs, p.hq, w[SUR_ST_WHI + 3 * g], nullptr, p.cs, 1, 1, L.gates + g * s, true);
+    STAMP(0);
+    // all four gates' pre-activations in ONE gather-GEMM: rows = (gate, channel), K = 3*(ca + cs).
+    // The four gates' weights are consecutive in the LDS copy (Wx_g, b_g, Wh_g per gate), so the
+    // row stride between gates is constant.
+    {
+        const int gate_stride = (int)(w[SUR_ST_WXF] - w[SUR_ST_WXI]);
+        const GemmSeg seg[2] = {{w[SUR_ST_WXI], p.ca * 3, 3, L.x, p.hq, p.ca}, {w[SUR_ST_WHI], p.cs * 3, 3, L.h, p.hq, p.cs}};
+        const int cs = p.cs, hq = p.hq, ca = p.ca;
+        // row m = g*cs + o lives at gate g's weight block: fold the gate offset into a_sm arithmetic by
+        // running one GEMM per gate tile row-block (cs is a multiple of 16 for this model family)
+        const int nwg = blockDim.x >> 6;
+        for (int g = 0; g < 4; ++g) {
+            const GemmSeg sg[2] = {{seg[0].a + g * gate_stride, ca * 3, 3, L.x, hq, ca},
+                                   {seg[1].a + g * gate_stride, cs * 3, 3, L.h, hq, cs}};
+            const float* bias = w[SUR_ST_BXI] + g * gate_stride;
+            float* outg = L.gates + g * s;
+            // gate g on its own wave quarter (all waves if the workgroup has fewer than 4)
+            const WaveSet ws = nwg >= 4 ? WaveSet{g * (nwg / 4), nwg / 4} : WaveSet{0, nwg};
+            gemm_taps<3, 2>(ws, false, cs, hq, sg, [&](int, int tap, int n) { return wrapi(n + tap - 1, hq); },
+                            [&](int m, int n, float v) {
+                                if (m < cs) outg[m * hq + n] = v + bias[m];
+                            });
+        }
+        __syncthreads();
     }
+    STAMP(1);
     for (int i = threadIdx.x; i < s; i += blockDim.x) {
         const float gi = sigmoid_(L.gates[i]), gf = sigmoid_(L.gates[s + i]), gg = tanhf(L.gates[2 * s + i]),
                     go = sigmoid_(L.gates[3 * s + i]);
@@ -611,13 +792,21 @@ __device__ void step_forward_body(const sur_chunk_params& p, const StepLayout& L
         L.hnew[i] = go * tanhf(cn);
     }
     __syncthreads();
+    STAMP(2);
     deconv_fwd(L.hnew, p.cs, p.hq, w[SUR_ST_DC0_W], w[SUR_ST_DC0_B], p.cs, L.p0);
+    STAMP(3);
     act_ln_fwd(L.p0, p.cs, 2 * p.hq, w[SUR_ST_LN0_W], w[SUR_ST_LN0_B], true, L.a0);
+    STAMP(4);
     deconv_fwd(L.a0, p.cs, 2 * p.hq, w[SUR_ST_DC1_W], w[SUR_ST_DC1_B], p.c_mid, L.p1);
+    STAMP(5);
     act_ln_fwd(L.p1, p.c_mid, L.n, w[SUR_ST_LN1_W], w[SUR_ST_LN1_B], true, L.a1);
+    STAMP(6);
     conv_fwd<7>(L.a1, p.c_mid, L.n, w[SUR_ST_CV2_W], w[SUR_ST_CV2_B], 1, 1, 3, L.p2, false);
+    STAMP(7);
     act_ln_fwd(L.p2, 1, L.n, w[SUR_ST_LN2_W], w[SUR_ST_LN2_B], true, L.a2);
+    STAMP(8);
     conv_fwd<5>(L.a2, 1, L.n, w[SUR_ST_CV3_W], w[SUR_ST_CV3_B], 1, 1, 2, L.d, false);
+    STAMP(9);
 }
 
 __global__ void __launch_bounds__(TPB)
@@ -647,6 +836,7 @@ chunk_fwd_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, con
         if (k < S)
             for (int i = threadIdx.x; i < n; i += blockDim.x) L.outv[i] = states_t[kb * n + i];
         __syncthreads();
+        STAMP(10);
         step_forward_body(p, L, v.w);
         for (int i = threadIdx.x; i < s; i += blockDim.x) {
             h_all[kb * s + i] = L.hnew[i];
@@ -660,6 +850,7 @@ chunk_fwd_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, con
             L.outv[i] = o;
         }
         __syncthreads();
+        STAMP(11);
     }
 }
 
@@ -708,17 +899,17 @@ chunk_bwd_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, con
         }
         __syncthreads();
         // ---- decoder backward ----
-        conv_bwd_weight<5>(L.gA, 1, L.a2, 1, n, 1, 2, g[SUR_ST_CV3_W], g[SUR_ST_CV3_B]);
+        conv_bwd_weight<5>(L.gA, 1, L.a2, 1, n, 1, 2, g[SUR_ST_CV3_W], g[SUR_ST_CV3_B], all_waves(), false);
         conv_bwd_data<5>(L.gA, 1, n, w[SUR_ST_CV3_W], 1, 1, 2, L.gB, false);
         act_ln_bwd(L.gB, L.p2, 1, n, w[SUR_ST_LN2_W], true, L.gA, L.xh, g[SUR_ST_LN2_W], g[SUR_ST_LN2_B]);
-        conv_bwd_weight<7>(L.gA, 1, L.a1, p.c_mid, n, 1, 3, g[SUR_ST_CV2_W], g[SUR_ST_CV2_B]);
+        conv_bwd_weight<7>(L.gA, 1, L.a1, p.c_mid, n, 1, 3, g[SUR_ST_CV2_W], g[SUR_ST_CV2_B], all_waves(), false);
         conv_bwd_data<7>(L.gA, 1, n, w[SUR_ST_CV2_W], p.c_mid, 1, 3, L.gB, false);
         act_ln_bwd(L.gB, L.p1, p.c_mid, n, w[SUR_ST_LN1_W], true, L.gA, L.xh, g[SUR_ST_LN1_W], g[SUR_ST_LN1_B]);
-        deconv_bwd_weight(L.gA, p.c_mid, L.a0, p.cs, 2 * p.hq, g[SUR_ST_DC1_W], g[SUR_ST_DC1_B]);
-        deconv_bwd_data(L.gA, p.c_mid, 2 * p.hq, w[SUR_ST_DC1_W], p.cs, L.gB);
+        deconv_bwd_weight(L.gA, p.c_mid, L.a0, p.cs, 2 * p.hq, g[SUR_ST_DC1_W], g[SUR_ST_DC1_B], lower_half(), false);
+        deconv_bwd_data(L.gA, p.c_mid, 2 * p.hq, w[SUR_ST_DC1_W], p.cs, L.gB, upper_half(), true);
         act_ln_bwd(L.gB, L.p0, p.cs, 2 * p.hq, w[SUR_ST_LN0_W], true, L.gA, L.xh, g[SUR_ST_LN0_W], g[SUR_ST_LN0_B]);
-        deconv_bwd_weight(L.gA, p.cs, L.hnew, p.cs, p.hq, g[SUR_ST_DC0_W], g[SUR_ST_DC0_B]);
-        deconv_bwd_data(L.gA, p.cs, p.hq, w[SUR_ST_DC0_W], p.cs, L.dh);
+        deconv_bwd_weight(L.gA, p.cs, L.hnew, p.cs, p.hq, g[SUR_ST_DC0_W], g[SUR_ST_DC0_B], lower_half(), false);
+        deconv_bwd_data(L.gA, p.cs, p.hq, w[SUR_ST_DC0_W], p.cs, L.dh, upper_half(), true);
 
         // ---- cell backward ----
         for (int i = threadIdx.x; i < s; i += blockDim.x) {
@@ -733,13 +924,76 @@ chunk_bwd_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, con
             L.dc_carry[i] = dcn * gf;  // gradient wrt c_{k-1}
         }
         __syncthreads();
-#pragma unroll
-        for (int gt = 0; gt < 4; ++gt) {
-            const float* dg = L.dgates + gt * s;
-            conv_bwd_weight<3>(dg, p.cs, L.x, p.ca, p.hq, 1, 1, g[SUR_ST_WXI + 3 * gt], g[SUR_ST_BXI + 3 * gt]);
-            conv_bwd_weight<3>(dg, p.cs, L.h, p.cs, p.hq, 1, 1, g[SUR_ST_WHI + 3 * gt], nullptr);
-            conv_bwd_data<3>(dg, p.cs, p.hq, w[SUR_ST_WXI + 3 * gt], p.ca, 1, 1, L.dx, gt > 0);
-            conv_bwd_data<3>(dg, p.cs, p.hq, w[SUR_ST_WHI + 3 * gt], p.cs, 1, 1, L.dhin, gt > 0);
+        {
+            // four independent GEMMs on the gate gradients dG [4*cs][hq], issued without barriers in between:
+            //   dx  [ca][hq]  = sum_g Wx_g^T * dG_g     (waves: first quarter)
+            //   dh  [cs][hq]  = sum_g Wh_g^T * dG_g     (second quarter)
+            //   gWx, gWh, gb  = dG_g x {x, h}           (second half)
+            const int nwg = blockDim.x >> 6, cs = p.cs, ca = p.ca, hq = p.hq;
+            const int gate_stride = (int)(w[SUR_ST_WXF] - w[SUR_ST_WXI]);
+            const WaveSet w_dx = nwg >= 4 ? WaveSet{0, nwg / 4} : all_waves();
+            const WaveSet w_dh = nwg >= 4 ? WaveSet{nwg / 4, nwg / 4} : all_waves();
+            const WaveSet w_gw = nwg >= 4 ? WaveSet{nwg / 2, nwg - nwg / 2} : all_waves();
+            auto tap_col = [&](int, int tap, int j) { return wrapi(j - tap + 1, hq); };  // stride 1, pad 1
+            {   // A[m=ci][c=o][tap] = W_g[(o*cin + ci)*3 + tap];  B = dG_g[o][col]
+                const float* wx = w[SUR_ST_WXI];
+                const GemmSeg sx[4] = {{wx, 3, ca * 3, L.dgates, hq, cs},
+                                       {wx + gate_stride, 3, ca * 3, L.dgates + s, hq, cs},
+                                       {wx + 2 * gate_stride, 3, ca * 3, L.dgates + 2 * s, hq, cs},
+                                       {wx + 3 * gate_stride, 3, ca * 3, L.dgates + 3 * s, hq, cs}};
+                float* dxp = L.dx;
+                gemm_taps<3, 4>(w_dx, false, ca, hq, sx, tap_col, [&](int m, int j, float v) {
+                    if (m < ca) dxp[m * hq + j] = v;
+                });
+                const float* wh = w[SUR_ST_WHI];
+                const GemmSeg sh[4] = {{wh, 3, cs * 3, L.dgates, hq, cs},
+                                       {wh + gate_stride, 3, cs * 3, L.dgates + s, hq, cs},
+                                       {wh + 2 * gate_stride, 3, cs * 3, L.dgates + 2 * s, hq, cs},
+                                       {wh + 3 * gate_stride, 3, cs * 3, L.dgates + 3 * s, hq, cs}};
+                float* dhp = L.dhin;
+                gemm_taps<3, 4>(w_dh, false, cs, hq, sh, tap_col, [&](int m, int j, float v) {
+                    if (m < cs) dhp[m * hq + j] = v;
+                });
+            }
+            // weight gradients, all gates in one GEMM each: rows m = (gate, o)
+            struct St { const float* row; int off; };
+            {
+                float* gx = g[SUR_ST_WXI];
+                const float* xin = L.x;
+                const int ncols = ca * 3;
+                gemm_pos(w_gw, false, 4 * cs, ncols, hq, L.dgates, hq,
+                         [&](int n) { const int ci = n / 3, k = n - ci * 3; return St{xin + ci * hq, k - 1}; },
+                         [&](const St& st, int pp) { return st.row[wrapi(pp + st.off, hq)]; },
+                         [&](int m, int n, float v) {
+                             if (m < 4 * cs && n < ncols) {
+                                 const int gt = m / cs, o = m - gt * cs;
+                                 gx[gt * gate_stride + o * ncols + n] += v;
+                             }
+                         });
+                float* gh = g[SUR_ST_WHI];
+                const float* hin_ = L.h;
+                const int ncols_h = cs * 3;
+                gemm_pos(w_gw, false, 4 * cs, ncols_h, hq, L.dgates, hq,
+                         [&](int n) { const int ci = n / 3, k = n - ci * 3; return St{hin_ + ci * hq, k - 1}; },
+                         [&](const St& st, int pp) { return st.row[wrapi(pp + st.off, hq)]; },
+                         [&](int m, int n, float v) {
+                             if (m < 4 * cs && n < ncols_h) {
+                                 const int gt = m / cs, o = m - gt * cs;
+                                 gh[gt * gate_stride + o * ncols_h + n] += v;
+                             }
+                         });
+                float* gbx = g[SUR_ST_BXI];
+                for (int idx = threadIdx.x; idx < 4 * cs; idx += blockDim.x) {
+                    const int gt = idx / cs, o = idx - gt * cs;
+                    float a0 = 0.0f, a1 = 0.0f;
+                    for (int pp = 0; pp < hq; pp += 2) {
+                        a0 += L.dgates[idx * hq + pp];
+                        a1 += L.dgates[idx * hq + pp + 1];
+                    }
+                    gbx[gt * gate_stride + o] += a0 + a1;
+                }
+            }
+            __syncthreads();
         }
         if (dxlat_t)
             for (int i = threadIdx.x; i < nx; i += blockDim.x) dxlat_t[kb * nx + i] = L.dx[i];
@@ -767,19 +1021,30 @@ chunk_bwd_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, con
 // g[i][j] += sum_r partial[r][off_i + j]; the partial rows are re-zeroed
 template <int NP, typename Params>
 __global__ void __launch_bounds__(TPB) flush_grads_kernel(const Params p, int psize) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= psize) return;
+    // block = 32 columns x 8 row groups: each thread sums every 8th row of its column, LDS combines the 8 partials
+    __shared__ float part[8][33];
+    const int col = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int t = blockIdx.x * 32 + col;
     float acc = 0.0f;
-    for (int r = 0; r < p.rows; ++r) {
-        float* q = p.partial + (size_t)r * psize + t;
-        acc += *q;
-        *q = 0.0f;
+    if (t < psize) {
+        for (int r = rg; r < p.rows; r += 8) {
+            float* q = p.partial + (size_t)r * psize + t;
+            acc += *q;
+            *q = 0.0f;
+        }
     }
-    int off = 0;
+    part[rg][col] = acc;
+    __syncthreads();
+    if (rg == 0 && t < psize) {
+        float tot = 0.0f;
 #pragma unroll
-    for (int i = 0; i < NP; ++i) {
-        if (t >= off && t < off + p.size[i]) p.g[i][t - off] += acc;
-        off += p.size[i];
+        for (int i = 0; i < 8; ++i) tot += part[i][col];
+        int off = 0;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            if (t >= off && t < off + p.size[i]) p.g[i][t - off] += tot;
+            off += p.size[i];
+        }
     }
 }
 
@@ -806,8 +1071,20 @@ extern "C" {
 
 const char* sur_last_error(void) { return g_err; }
 
+#ifdef SUR_STAMP
+int sur_debug_stamps(long long* out32, int reset) {
+    if (out32 && hipMemcpyFromSymbol(out32, HIP_SYMBOL(sur_stamp_buf), sizeof(long long) * 32) != hipSuccess) return -2;
+    if (reset) {
+        long long z[32] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(sur_stamp_buf), z, sizeof(z)) != hipSuccess) return -2;
+    }
+    return 0;
+}
+#endif
+
 int sur_encoder_forward(void* stream, const sur_encoder_params* p, const float* x, int m, float* z) {
     if (!p || !x || !z || m <= 0) return fail(-1, "sur_encoder_forward: bad argument");
+    if (p->n > 64 * LN_MAX_EPL * p->stride[0]) return fail(-4, "sur_encoder_forward: N = %d too wide for the fused LayerNorm", p->n);
     const int psize = psize_of<SUR_ENC_NPARAM>(p->size);
     const size_t lds = sizeof(float) * (enc_act_floats(*p, false) + psize);
     if (int rc = set_lds(enc_fwd_kernel, lds, "encoder forward")) return rc;
@@ -836,7 +1113,7 @@ int sur_flush_encoder_grads(void* stream, const sur_encoder_params* p) {
         if (!p->g[i]) return fail(-1, "sur_flush_encoder_grads: gradient tensor %d is NULL", i);
     const int psize = psize_of<SUR_ENC_NPARAM>(p->size);
     return launch_checked([&] {
-        hipLaunchKernelGGL((flush_grads_kernel<SUR_ENC_NPARAM, sur_encoder_params>), dim3((psize + TPB - 1) / TPB), dim3(TPB), 0,
+        hipLaunchKernelGGL((flush_grads_kernel<SUR_ENC_NPARAM, sur_encoder_params>), dim3((psize + 31) / 32), dim3(TPB), 0,
                            (hipStream_t)stream, *p, psize);
     }, "flush_enc");
 }
@@ -847,6 +1124,7 @@ int sur_chunk_forward(void* stream, const sur_chunk_params* p, const float* xlat
     if (!p || !xlat_t || !h0 || !c0 || !h_all || !c_all || !d_all || !out_all || k <= 0 || b <= 0 || s < 1 ||
         !lstates_t || !states_t)
         return fail(-1, "sur_chunk_forward: bad argument (need K > 0, B > 0, S >= 1)");
+    if (4 * p->hq > 64 * LN_MAX_EPL) return fail(-4, "sur_chunk_forward: N = %d too wide for the fused LayerNorm", 4 * p->hq);
     const int psize = psize_of<SUR_ST_NPARAM>(p->size);
     const size_t lds = sizeof(float) * (step_act_floats(*p, false) + psize);
     if (int rc = set_lds(chunk_fwd_kernel, lds, "chunk forward")) return rc;
@@ -880,7 +1158,7 @@ int sur_flush_chunk_grads(void* stream, const sur_chunk_params* p) {
         if (!p->g[i]) return fail(-1, "sur_flush_chunk_grads: gradient tensor %d is NULL", i);
     const int psize = psize_of<SUR_ST_NPARAM>(p->size);
     return launch_checked([&] {
-        hipLaunchKernelGGL((flush_grads_kernel<SUR_ST_NPARAM, sur_chunk_params>), dim3((psize + TPB - 1) / TPB), dim3(TPB), 0,
+        hipLaunchKernelGGL((flush_grads_kernel<SUR_ST_NPARAM, sur_chunk_params>), dim3((psize + 31) / 32), dim3(TPB), 0,
                            (hipStream_t)stream, *p, psize);
     }, "flush_chunk");
 }

@@ -73,7 +73,7 @@ def test_fused_encoder_forward_backward(dev, which, N):
     got = _grads(m)
     for k, v in ref_g.items():
         if k.startswith(which):
-            _close(got[k], v, msg=k)
+            _close(got[k], v, atol_scale=8e-5, msg=k)
 
 
 @pytest.mark.parametrize("N", [64, 256])
@@ -123,7 +123,9 @@ def test_fused_chunk_forward_backward(dev, N, K, S):
     got = _grads(m)
     for k, v in ref_g.items():
         if k.startswith(("transition_model", "state_decoder")):
-            _close(got[k], v, msg=k)
+            # parameter gradients are long fp32 sums (space x time) with cancellation: summation order
+            # (MFMA k-order vs MIOpen) moves them by a few 1e-5 of the tensor's scale
+            _close(got[k], v, atol_scale=8e-5, msg=k)
 
 
 def test_fused_training_step_matches_unfused_and_golden(dev, sur_golden):
