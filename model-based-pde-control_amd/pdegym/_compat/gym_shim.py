@@ -54,8 +54,7 @@ def batch_space(space, n):
 class Env:
     metadata = {}
     reward_range = (-float("inf"), float("inf"))
-    action_space = None
-    observation_space = None
+    # (no class-level action_space / observation_space: wrappers forward them through __getattr__)
 
     def __init__(self, *args, **kwargs):
         pass

@@ -395,10 +395,70 @@ def surrogate_fixtures(tr):
     return out
 
 
+# --------------------------------------------------------------------------- #
+# vector-wrapper fixtures
+# --------------------------------------------------------------------------- #
+def run_wrapper_scenario(W, T, gym, fake_factory, actions):
+    """Stack of pdecontrol/mbrl/mbrl.py:259-272 (minus the world-model wrapper) on the scripted fake
+    env; records every observable array after reset and after each step."""
+    env = fake_factory(gym)
+    # transforms exactly as the controller builds them (mbrl.py:146-175)
+    ostore = W.StoreNObsVecWrapper(env, num_steps=2)
+    oscaling = T.ScaleTransform(batched=True, aggregate=True, frozen=False)
+    e = W.TransformObsWrapper(ostore, oscaling, frozen=False)
+    e = W.TransformObsWrapper(e, T.BatchTransform(T.SensorTransform(stride=1)))
+    e = W.TransformObsWrapper(e, T.BatchTransform(T.SensorTransform(stride=2)))
+    astore = W.StoreNActionsVecWrapper(e, num_steps=2)
+    low = env.single_action_space.low[np.newaxis, ...] * 2.0
+    high = env.single_action_space.high[np.newaxis, ...] * 2.0
+    ascaling = T.ScaleTransform(bounds=(low, high), aggregate=True, frozen=True, batched=True).Inverse
+    top = W.TransformActionWrapper(astore, ascaling, frozen=True)
+    rec = {}
+    obs, info = top.reset(return_info=True)
+    rec["reset_obs"], rec["reset_step"] = np.asarray(obs), np.asarray(info["step"])
+    rec["obs_space_shape"] = np.asarray(top.observation_space.shape)
+    rec["act_low"], rec["act_high"] = np.asarray(top.action_space.low), np.asarray(top.action_space.high)
+    for k, a in enumerate(actions):
+        top.step_async(a)
+        obs, rew, term, trunc, infos = top.step_wait()
+        rec[f"s{k}_obs"], rec[f"s{k}_rew"], rec[f"s{k}_trunc"] = np.asarray(obs), np.asarray(rew), np.asarray(trunc)
+        rec[f"s{k}_step"] = np.asarray(infos["step"])
+        rec[f"s{k}_has_final"] = np.asarray("final_observation" in infos)
+        if "final_observation" in infos:
+            rec[f"s{k}_final"] = np.asarray(list(infos["final_observation"]), dtype=np.float32)
+        rec[f"s{k}_ostore_obs"], rec[f"s{k}_ostore_mask"] = ostore.obs.copy(), ostore.mask.copy()
+        rec[f"s{k}_ostore_finals"] = ostore.finals.copy()
+        rec[f"s{k}_astore_actions"], rec[f"s{k}_astore_mask"] = astore.actions.copy(), astore.mask.copy()
+        rec[f"s{k}_vmin"] = np.asarray(oscaling.vmin).copy()
+        rec[f"s{k}_vmax"] = np.asarray(oscaling.vmax).copy()
+    return rec
+
+
+def wrapper_fixtures():
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "..", "tests"))
+    sys.path.insert(0, os.path.join(here, "..", "model-based-pde-control_amd"))
+    import _fake_vec_env as fk
+    # the reference file needs only gym.vector.{VectorEnv,VectorEnvWrapper} and gym.spaces.Box: give it
+    # this repo's shim classes (so that both wrapper sets sit on identical base classes), and the
+    # numpy-1.x alias it uses
+    shim_spec = importlib.util.spec_from_file_location(
+        "_gym_shim_for_ref", os.path.join(here, "..", "model-based-pde-control_amd", "pdegym", "_compat", "gym_shim.py"))
+    shim = importlib.util.module_from_spec(shim_spec)
+    shim_spec.loader.exec_module(shim)
+    sys.modules["gym"] = shim
+    if not hasattr(np, "bool8"):
+        np.bool8 = np.bool_
+    W = _load("pdegym.common.vec_wrappers", "pdegym/common/vec_wrappers.py")
+    import pdegym.common.transforms as T  # the reference's (package path points at /root/reference)
+    actions = fk.scripted_actions(3, 7)
+    return run_wrapper_scenario(W, T, shim, fk.make_fake_vec_env, actions)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-reset", action="store_true", help="skip the two ~50 s burn-in resets")
-    ap.add_argument("--only", choices=["ks", "surrogate"], default=None)
+    ap.add_argument("--only", choices=["ks", "surrogate", "wrappers"], default=None)
     args = ap.parse_args()
     if not os.path.isdir(REF):
         sys.exit("reference not present: fixtures can only be generated in the build container")
@@ -414,6 +474,10 @@ def main():
         fx = surrogate_fixtures(tr)
         np.savez_compressed(os.path.join(OUT, "surrogate_golden.npz"), **fx)
         print("surrogate_golden.npz:", len(fx), "arrays")
+    if args.only in (None, "wrappers"):
+        fx = wrapper_fixtures()
+        np.savez_compressed(os.path.join(OUT, "wrappers_golden.npz"), **fx)
+        print("wrappers_golden.npz:", len(fx), "arrays")
 
 
 if __name__ == "__main__":
