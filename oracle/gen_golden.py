@@ -455,10 +455,25 @@ def wrapper_fixtures():
     return run_wrapper_scenario(W, T, shim, fk.make_fake_vec_env, actions)
 
 
+def dataset_fixtures():
+    """replay -> sub-sequence datasets -> loaders, and the curriculum schedulers."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "..", "tests"))
+    import _dataset_scenario as sc
+    if not hasattr(np, "bool8"):
+        np.bool8 = np.bool_
+    import pdecontrol.mbrl.replay as replay
+    import pdecontrol.surrogates.common.dataset as ds
+    import pdecontrol.surrogates.common.schedulers as sched
+    from pdecontrol.mbrl.types import Sample
+    rec, _ = sc.run(replay.ExperienceReplay, ds, sched, Sample)
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-reset", action="store_true", help="skip the two ~50 s burn-in resets")
-    ap.add_argument("--only", choices=["ks", "surrogate", "wrappers"], default=None)
+    ap.add_argument("--only", choices=["ks", "surrogate", "wrappers", "dataset"], default=None)
     args = ap.parse_args()
     if not os.path.isdir(REF):
         sys.exit("reference not present: fixtures can only be generated in the build container")
@@ -474,6 +489,10 @@ def main():
         fx = surrogate_fixtures(tr)
         np.savez_compressed(os.path.join(OUT, "surrogate_golden.npz"), **fx)
         print("surrogate_golden.npz:", len(fx), "arrays")
+    if args.only in (None, "dataset"):
+        fx = dataset_fixtures()
+        np.savez_compressed(os.path.join(OUT, "dataset_golden.npz"), **fx)
+        print("dataset_golden.npz:", len(fx), "arrays")
     if args.only in (None, "wrappers"):
         fx = wrapper_fixtures()
         np.savez_compressed(os.path.join(OUT, "wrappers_golden.npz"), **fx)
