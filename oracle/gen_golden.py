@@ -470,10 +470,48 @@ def dataset_fixtures():
     return rec
 
 
+def world_fixtures(ks):
+    """WorldVecEnv (imagined rollouts) driven through a scripted scenario."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "..", "tests"))
+    import _world_scenario as sc
+    if not hasattr(np, "bool8"):
+        np.bool8 = np.bool_
+    # world.py needs gym.vector.VectorEnv and gym.vector.utils.spaces.batch_space: take both from the
+    # repo's shim (module stubs only, no reference code is replaced)
+    shim_spec = importlib.util.spec_from_file_location(
+        "_gym_shim_for_ref2", os.path.join(here, "..", "model-based-pde-control_amd", "pdegym", "_compat", "gym_shim.py"))
+    shim = importlib.util.module_from_spec(shim_spec)
+    shim_spec.loader.exec_module(shim)
+    gym = sys.modules["gym"]
+    gym.vector = types.ModuleType("gym.vector")
+    gym.vector.VectorEnv = shim.VectorEnv
+    gym.vector.VectorEnvWrapper = shim.VectorEnvWrapper
+    utils = types.ModuleType("gym.vector.utils")
+    spaces = types.ModuleType("gym.vector.utils.spaces")
+    spaces.batch_space = shim.batch_space
+    utils.spaces = spaces
+    gym.vector.utils = utils
+    gym.spaces.Box = shim.Box
+    sys.modules.update({"gym.vector": gym.vector, "gym.vector.utils": utils, "gym.vector.utils.spaces": spaces})
+    import pdecontrol.mbrl.replay as replay
+    import pdecontrol.surrogates.common.dataset as ds
+    import pdegym.common.transforms as T
+    from pdecontrol.architectures.autoreg import KSAutoRegConvolutionalLSTM
+    from pdecontrol.mbrl.types import Sample
+    from pdecontrol.mbrl.world.world import WorldVecEnv
+    from pdecontrol.surrogates.surrogate import PDEEnsemble
+    from pdecontrol.surrogates.training import PDETrainingModule
+    M = types.SimpleNamespace(Env=ks.KuramotoSivashinskyEnv, T=T, Replay=replay.ExperienceReplay, ds=ds, Sample=Sample,
+                              factory_cls=KSAutoRegConvolutionalLSTM, TrainingModule=PDETrainingModule,
+                              Ensemble=PDEEnsemble, WorldVecEnv=WorldVecEnv)
+    return sc.run(M)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-reset", action="store_true", help="skip the two ~50 s burn-in resets")
-    ap.add_argument("--only", choices=["ks", "surrogate", "wrappers", "dataset"], default=None)
+    ap.add_argument("--only", choices=["ks", "surrogate", "wrappers", "dataset", "world"], default=None)
     args = ap.parse_args()
     if not os.path.isdir(REF):
         sys.exit("reference not present: fixtures can only be generated in the build container")
@@ -489,6 +527,11 @@ def main():
         fx = surrogate_fixtures(tr)
         np.savez_compressed(os.path.join(OUT, "surrogate_golden.npz"), **fx)
         print("surrogate_golden.npz:", len(fx), "arrays")
+    if args.only in (None, "world"):
+        ksm = _load("pdegym.kuramoto.kuramoto", "pdegym/kuramoto/kuramoto.py")
+        fx = world_fixtures(ksm)
+        np.savez_compressed(os.path.join(OUT, "world_golden.npz"), **fx)
+        print("world_golden.npz:", len(fx), "arrays")
     if args.only in (None, "dataset"):
         fx = dataset_fixtures()
         np.savez_compressed(os.path.join(OUT, "dataset_golden.npz"), **fx)
