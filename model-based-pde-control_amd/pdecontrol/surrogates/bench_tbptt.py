@@ -112,3 +112,40 @@ def run(device, steps=50, warmup=5, B=64, cpu_steps=3):
                            "sample": f"same nn.Module tree + training_step + Adam on torch CPU kernels, "
                                      f"{cpu_steps} steps, best of 1 / 16 threads"}
     return res
+
+
+def run_ddp(device, steps=100, warmup=5, B=64):
+    """Data-parallel TBPTT (weak scaling: B sequences per rank): fused fwd/bwd graph -> ONE all-reduce of the
+    flat 38 956-byte gradient bucket (RCCL over xGMI) -> Adam graph.  Call on every rank of an initialised
+    process group; returns this rank's seconds per step."""
+    import torch.distributed as dist
+    from pdecontrol.surrogates import ops
+    from pdecontrol.surrogates.distributed import broadcast_parameters
+    from pdecontrol.surrogates.graph_step import GraphedTBPTTStep
+    rank = dist.get_rank()
+    g = torch.Generator().manual_seed(1000 + rank)
+    s = (torch.rand(B, 20, 1, 64, generator=g) * 2 - 1).to(device)
+    a = (torch.rand(B, 20, 1, 64, generator=g) * 2 - 1).to(device)
+    try:
+        ops.enable_fused(True)
+        module = build_module(device)
+        broadcast_parameters(module.surrogate)
+        graphed = GraphedTBPTTStep(module, tuple(s.shape), distributed=True)
+        graphed.step(s, a)
+        for _ in range(warmup):
+            graphed.step()
+        torch.cuda.synchronize(device)
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            graphed.step()
+        torch.cuda.synchronize(device)
+        dt = (time.perf_counter() - t0) / steps
+        # every rank must hold identical parameters after identical all-reduced updates
+        flat = torch.cat([p.detach().reshape(-1) for p in module.surrogate.parameters()])
+        ref = flat.clone()
+        dist.broadcast(ref, src=0)
+        in_sync = bool(torch.equal(flat, ref))
+    finally:
+        ops.enable_fused(False)
+    return dt, in_sync, float(graphed.result["loss"].detach())

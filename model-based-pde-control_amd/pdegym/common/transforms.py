@@ -295,9 +295,23 @@ class BatchTransform(Transform):
         return self._map(self.transform, values)
 
     def update(self, values):
+        inner = self.transform
+        if type(inner).update is Transform.update:
+            return                      # stateless inner transform: nothing to update (and no per-item loop)
         t, _ = _to_tensor(values)
-        for item in t:
-            self.transform.update(item)
+        if isinstance(inner, ScaleTransform):
+            # running min / max are exact and order-independent: reduce every item at once, then fold
+            # the per-item extrema -- same result as updating item by item, without the Python loop
+            if inner.frozen or t.shape[0] == 0:
+                return
+            dims = tuple(d + 1 for d in inner.dim)
+            lo = torch.amin(torch.amin(t, dim=dims, keepdim=True), dim=0)
+            hi = torch.amax(torch.amax(t, dim=dims, keepdim=True), dim=0)
+            inner.vmin = lo if bool(torch.all(torch.isneginf(inner.vmin))) else torch.minimum(lo, _on(inner.vmin, t))
+            inner.vmax = hi if bool(torch.all(torch.isposinf(inner.vmax))) else torch.maximum(hi, _on(inner.vmax, t))
+            return
+        for item in t:                  # order-dependent running statistics (Normalize): item by item
+            inner.update(item)
 
 
 class _OperationInverse(_InverseView):
