@@ -70,9 +70,11 @@ typedef struct sur_chunk_params {
 } sur_chunk_params;
 
 int sur_encoder_forward(void* stream, const sur_encoder_params* p, const float* x, int m, float* z);
-/* dx may be NULL (raw data input).  Accumulates parameter gradients into p->partial. */
+/* dx may be NULL (raw data input).  Accumulates parameter gradients into rows
+ * [row_base, row_base + row_count) of p->partial (one row per workgroup; launches that may run
+ * concurrently on different streams must be given disjoint row ranges). */
 int sur_encoder_backward(void* stream, const sur_encoder_params* p, const float* x, const float* dz, int m,
-                         float* dx);
+                         float* dx, int row_base, int row_count);
 int sur_flush_encoder_grads(void* stream, const sur_encoder_params* p);
 
 /* Time-major tensors: xlat_t [K,B,ca,hq]; lstates_t [S,B,cs,hq] (encoded given states, S >= 1);
@@ -83,11 +85,12 @@ int sur_chunk_forward(void* stream, const sur_chunk_params* p, const float* xlat
                       float* c_all, float* d_all, float* out_all);
 /* Upstream gradients (each may be NULL = 0): dd_all / dout_all [K,B,1,N] wrt d_all / out_all;
  * dh_all / dc_all [K,B,cs,hq] wrt h_all / c_all.  Outputs (each may be NULL): dxlat_t [K,B,ca,hq],
- * dlstates_t [S,B,cs,hq], dh0, dc0 [B,cs,hq].  Accumulates parameter gradients into p->partial. */
+ * dlstates_t [S,B,cs,hq], dh0, dc0 [B,cs,hq].  Accumulates parameter gradients into rows
+ * [row_base, row_base + B) of p->partial. */
 int sur_chunk_backward(void* stream, const sur_chunk_params* p, const float* xlat_t, const float* lstates_t,
                        const float* h0, const float* c0, const float* h_all, const float* c_all,
                        const float* dd_all, const float* dout_all, const float* dh_all, const float* dc_all, int k,
-                       int s, int b, float* dxlat_t, float* dlstates_t, float* dh0, float* dc0);
+                       int s, int b, float* dxlat_t, float* dlstates_t, float* dh0, float* dc0, int row_base);
 int sur_flush_chunk_grads(void* stream, const sur_chunk_params* p);
 
 const char* sur_last_error(void);

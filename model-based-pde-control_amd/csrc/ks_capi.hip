@@ -352,12 +352,11 @@ int ks_state_device_ptr(ks_handle* h, double** d_u) {
 }
 
 static int step_common(ks_handle* h, const float* d_phi, const float* d_act, const int* d_ids, int n_rows,
-                       long n_substeps, float* obs_f32, double* ssq_sum, int* status, bool compact_rows) {
+                       long n_substeps, float* obs_f32, double* ssq_sum, int* status) {
     int rc = do_step(h, d_phi, d_act, d_ids, n_rows, n_substeps, obs_f32 ? h->d_obs : nullptr,
                      ssq_sum ? h->d_ssq : nullptr, status ? h->d_status : nullptr);
     if (rc != KS_OK) return rc;
     const int rows = d_ids ? n_rows : h->E;
-    (void)compact_rows;
     if (!d_ids) {
         if (obs_f32)
             KS_HIP(hipMemcpyAsync(obs_f32, h->d_obs, sizeof(float) * (size_t)rows * h->N, hipMemcpyDeviceToHost,
@@ -380,7 +379,7 @@ int ks_step(ks_handle* h, const float* phi_host, long n_substeps, float* obs_f32
                               h->stream));
         d_phi = h->d_phi;
     }
-    return step_common(h, d_phi, nullptr, nullptr, 0, n_substeps, obs_f32, ssq_sum, status, false);
+    return step_common(h, d_phi, nullptr, nullptr, 0, n_substeps, obs_f32, ssq_sum, status);
 }
 
 int ks_step_actions(ks_handle* h, const float* actions_host, long n_substeps, float* obs_f32, double* ssq_sum,
@@ -390,7 +389,7 @@ int ks_step_actions(ks_handle* h, const float* actions_host, long n_substeps, fl
     DeviceGuard g(h->device);
     KS_HIP(hipMemcpyAsync(h->d_act, actions_host, sizeof(float) * (size_t)h->E * h->n_act, hipMemcpyHostToDevice,
                           h->stream));
-    return step_common(h, nullptr, h->d_act, nullptr, 0, n_substeps, obs_f32, ssq_sum, status, false);
+    return step_common(h, nullptr, h->d_act, nullptr, 0, n_substeps, obs_f32, ssq_sum, status);
 }
 
 int ks_step_rows(ks_handle* h, const int* env_ids_host, int n, long n_substeps, float* obs_f32, double* ssq_sum,
@@ -403,7 +402,7 @@ int ks_step_rows(ks_handle* h, const int* env_ids_host, int n, long n_substeps, 
             return fail(KS_ERR_INVALID, "env id %d out of range", env_ids_host[i]);
     DeviceGuard g(h->device);
     KS_HIP(hipMemcpyAsync(h->d_ids, env_ids_host, sizeof(int) * n, hipMemcpyHostToDevice, h->stream));
-    int rc = step_common(h, nullptr, nullptr, h->d_ids, n, n_substeps, obs_f32, ssq_sum, status, true);
+    int rc = step_common(h, nullptr, nullptr, h->d_ids, n, n_substeps, obs_f32, ssq_sum, status);
     if (rc != KS_OK) return rc;
     // outputs are indexed by env id on the device; hand them back compacted in list order
     const size_t row = sizeof(float) * (size_t)h->N;

@@ -662,14 +662,14 @@ __global__ void __launch_bounds__(TPB) enc_fwd_kernel(const sur_encoder_params p
 
 __global__ void __launch_bounds__(TPB) enc_bwd_kernel(const sur_encoder_params p, const float* __restrict__ x,
                                                       const float* __restrict__ dz, int m_total, float* __restrict__ dx,
-                                                      int grads_in_lds) {
+                                                      int grads_in_lds, int row_base) {
     extern __shared__ __align__(16) float lds[];
     EncLayout L;
     enc_layout(p, lds, true, L);
     ParamViews<SUR_ENC_NPARAM> v;
     stage_weights<SUR_ENC_NPARAM>(p.w, p.size, L.end, v);
     const int psize = psize_of<SUR_ENC_NPARAM>(p.size);
-    float* row = p.partial + (size_t)blockIdx.x * psize;
+    float* row = p.partial + (size_t)(row_base + blockIdx.x) * psize;
     float* gacc = grads_in_lds ? L.end + psize : row;
     setup_grads<SUR_ENC_NPARAM>(p.size, gacc, grads_in_lds != 0, v);
     const int nin = p.c[0] * p.n, nout = L.rb[2].cout * L.rb[2].hout;
@@ -860,14 +860,14 @@ chunk_bwd_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, con
                  const float* __restrict__ c_all, const float* __restrict__ dd_all, const float* __restrict__ dout_all,
                  const float* __restrict__ dh_all, const float* __restrict__ dc_all, int K, int S, int B,
                  float* __restrict__ dxlat_t, float* __restrict__ dlstates_t, float* __restrict__ dh0,
-                 float* __restrict__ dc0, int grads_in_lds) {
+                 float* __restrict__ dc0, int grads_in_lds, int row_base) {
     extern __shared__ __align__(16) float lds[];
     StepLayout L;
     step_layout(p, lds, true, L);
     ParamViews<SUR_ST_NPARAM> v;
     stage_weights<SUR_ST_NPARAM>(p.w, p.size, L.end, v);
     const int psize = psize_of<SUR_ST_NPARAM>(p.size);
-    float* row = p.partial + (size_t)blockIdx.x * psize;
+    float* row = p.partial + (size_t)(row_base + blockIdx.x) * psize;
     float* gacc = grads_in_lds ? L.end + psize : row;
     setup_grads<SUR_ST_NPARAM>(p.size, gacc, grads_in_lds != 0, v);
     const float* const* w = v.w;
@@ -1093,17 +1093,21 @@ int sur_encoder_forward(void* stream, const sur_encoder_params* p, const float* 
                           "enc_fwd");
 }
 
-int sur_encoder_backward(void* stream, const sur_encoder_params* p, const float* x, const float* dz, int m, float* dx) {
+int sur_encoder_backward(void* stream, const sur_encoder_params* p, const float* x, const float* dz, int m, float* dx,
+                         int row_base, int row_count) {
     if (!p || !x || !dz || m <= 0) return fail(-1, "sur_encoder_backward: bad argument");
-    if (!p->partial || p->rows <= 0) return fail(-1, "sur_encoder_backward: no partial gradient buffer");
+    if (!p->partial || row_count <= 0 || row_base < 0 || row_base + row_count > p->rows)
+        return fail(-1, "sur_encoder_backward: partial rows [%d, %d) outside the buffer of %d rows", row_base,
+                    row_base + row_count, p ? p->rows : 0);
     const int psize = psize_of<SUR_ENC_NPARAM>(p->size);
     const size_t base = sizeof(float) * (enc_act_floats(*p, true) + psize);
     int grads_in_lds = (base + sizeof(float) * psize <= LDS_LIMIT) ? 1 : 0;
     const size_t lds = base + (grads_in_lds ? sizeof(float) * psize : 0);
     if (int rc = set_lds(enc_bwd_kernel, lds, "encoder backward")) return rc;
-    const int grid = m < p->rows ? m : p->rows;
+    const int grid = m < row_count ? m : row_count;
     return launch_checked([&] {
-        hipLaunchKernelGGL(enc_bwd_kernel, dim3(grid), dim3(TPB), lds, (hipStream_t)stream, *p, x, dz, m, dx, grads_in_lds);
+        hipLaunchKernelGGL(enc_bwd_kernel, dim3(grid), dim3(TPB), lds, (hipStream_t)stream, *p, x, dz, m, dx, grads_in_lds,
+                           row_base);
     }, "enc_bwd");
 }
 
@@ -1137,10 +1141,11 @@ int sur_chunk_forward(void* stream, const sur_chunk_params* p, const float* xlat
 int sur_chunk_backward(void* stream, const sur_chunk_params* p, const float* xlat_t, const float* lstates_t,
                        const float* h0, const float* c0, const float* h_all, const float* c_all, const float* dd_all,
                        const float* dout_all, const float* dh_all, const float* dc_all, int k, int s, int b,
-                       float* dxlat_t, float* dlstates_t, float* dh0, float* dc0) {
+                       float* dxlat_t, float* dlstates_t, float* dh0, float* dc0, int row_base) {
     if (!p || !xlat_t || !lstates_t || !h0 || !c0 || !h_all || !c_all || k <= 0 || b <= 0 || s < 1)
         return fail(-1, "sur_chunk_backward: bad argument");
-    if (!p->partial || p->rows < b) return fail(-1, "sur_chunk_backward: partial gradient buffer has %d rows, need %d", p->rows, b);
+    if (!p->partial || row_base < 0 || p->rows < row_base + b)
+        return fail(-1, "sur_chunk_backward: partial gradient buffer has %d rows, need [%d, %d)", p->rows, row_base, row_base + b);
     const int psize = psize_of<SUR_ST_NPARAM>(p->size);
     const size_t base = sizeof(float) * (step_act_floats(*p, true) + psize);
     int grads_in_lds = (base + sizeof(float) * psize <= LDS_LIMIT) ? 1 : 0;
@@ -1148,7 +1153,7 @@ int sur_chunk_backward(void* stream, const sur_chunk_params* p, const float* xla
     if (int rc = set_lds(chunk_bwd_kernel, lds, "chunk backward")) return rc;
     return launch_checked([&] {
         hipLaunchKernelGGL(chunk_bwd_kernel, dim3(b), dim3(TPB), lds, (hipStream_t)stream, *p, xlat_t, lstates_t, h0, c0, h_all,
-                           c_all, dd_all, dout_all, dh_all, dc_all, k, s, b, dxlat_t, dlstates_t, dh0, dc0, grads_in_lds);
+                           c_all, dd_all, dout_all, dh_all, dc_all, k, s, b, dxlat_t, dlstates_t, dh0, dc0, grads_in_lds, row_base);
     }, "chunk_bwd");
 }
 

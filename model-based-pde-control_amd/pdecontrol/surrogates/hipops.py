@@ -41,10 +41,11 @@ class ChunkParams(ctypes.Structure):
 _EP, _CP, _i = ctypes.POINTER(EncoderParams), ctypes.POINTER(ChunkParams), ctypes.c_int
 SYMBOLS = (
     ("sur_encoder_forward", [_fp, _EP, _fp, _i, _fp]),
-    ("sur_encoder_backward", [_fp, _EP, _fp, _fp, _i, _fp]),
+    ("sur_encoder_backward", [_fp, _EP, _fp, _fp, _i, _fp, _i, _i]),
     ("sur_flush_encoder_grads", [_fp, _EP]),
     ("sur_chunk_forward", [_fp, _CP, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _fp, _fp, _fp, _fp]),
-    ("sur_chunk_backward", [_fp, _CP, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _fp, _fp, _fp, _fp]),
+    ("sur_chunk_backward", [_fp, _CP, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _fp, _fp, _fp, _fp,
+                            _i]),
     ("sur_flush_chunk_grads", [_fp, _CP]),
 )
 _lib = None
@@ -225,6 +226,10 @@ class FusedPacks:
             pack.refresh()
         self.chunk.c.mul, self.chunk.c.add = _dscale_constants(surrogate.dscaling)
 
+    def refresh_partials(self):
+        for pack in self.packs:
+            pack.c.partial, pack.c.rows = pack.partial.data_ptr(), pack.partial.shape[0]
+
     def flush(self):
         """Reduce every pending partial-gradient row into param.grad (3 tiny launches at most)."""
         self._flush_queued = False
@@ -269,7 +274,7 @@ class _EncoderFn(torch.autograd.Function):
         (x,) = ctx.saved_tensors
         dx = torch.empty_like(x) if ctx.need_dx else None
         _check(load().sur_encoder_backward(_stream(), ctypes.byref(ctx.pack.c), _p(x), _p(dz.contiguous()), x.shape[0],
-                                           _p(dx)))
+                                           _p(dx), 0, min(ENCODER_ROWS, ctx.pack.c.rows)))
         ctx.pack.dirty = True
         ctx.owner.schedule_flush()
         return dx, None, None, None
@@ -310,7 +315,7 @@ class _ChunkFn(torch.autograd.Function):
         k, b = xlat_t.shape[:2]
         _check(load().sur_chunk_backward(_stream(), ctypes.byref(ctx.pack.c), _p(xlat_t), _p(lstates_t), _p(h0), _p(c0),
                                          _p(h_all), _p(c_all), _p(dd_all), _p(dout_all), _p(dh_all), _p(dc_all), k,
-                                         lstates_t.shape[0], b, _p(dxlat), _p(dlst), _p(dh0), _p(dc0)))
+                                         lstates_t.shape[0], b, _p(dxlat), _p(dlst), _p(dh0), _p(dc0), 0))
         ctx.pack.dirty = True
         ctx.owner.schedule_flush()
         return dxlat, dlst, None, dh0, dc0, None, None, None
@@ -349,3 +354,147 @@ def fused_rollout(surrogate, states, actions, times, targets, hidden):
     by_batch = lambda t: take_steps(t.transpose(0, 1), pick)
     return ModelRollout(inlatents=None, outlatents=by_batch(h_all), deltas=by_batch(d_all), outputs=by_batch(out_all),
                         hidden=(h_all[-1], c_all[-1]))
+
+
+# ---------------------------------------------------------------------------------------------
+# whole TBPTT forward/backward as ONE autograd node with hand-scheduled streams
+# ---------------------------------------------------------------------------------------------
+_SIDE_STREAMS = {}
+
+
+def _side_streams(device, n):
+    pool = _SIDE_STREAMS.setdefault(device, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=device))
+    return pool[:n]
+
+
+class _Fork:
+    """``with _Fork(stream): ...`` -- run the block on ``stream`` after everything queued so far on the
+    current stream; ``join()`` makes the current stream wait for it.  Works eagerly and under hipGraph
+    capture (the side work becomes a parallel branch of the graph)."""
+
+    def __init__(self, stream):
+        self.stream = stream
+        self.main = torch.cuda.current_stream(stream.device)
+
+    def __enter__(self):
+        self.stream.wait_stream(self.main)
+        self.ctx = torch.cuda.stream(self.stream)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        self.ctx.__exit__(*exc)
+
+    def join(self):
+        self.main.wait_stream(self.stream)
+
+
+class _TBPTTFn(torch.autograd.Function):
+    """All chunks of a truncated-BPTT forward pass (training.py:71-98) and their backward.
+
+    Forward: the state encoder of chunk 0 and the action encoder of ALL T steps run concurrently; then
+    chunk kernel, (1-state) encoder, chunk kernel, ...  Backward: TBPTT cuts the graph between chunks, so
+    the chunks' backward kernels are independent -- they run concurrently on side streams, each followed
+    by its state-encoder backward; the single action-encoder backward joins them.  Concurrent launches
+    get disjoint partial-gradient row ranges."""
+
+    @staticmethod
+    def forward(ctx, states, actions, anchor, owner, surrogate, tau, tbtt):
+        b, t_total, _, n = actions.shape
+        cs, hq, ca = owner.chunk.c.cs, owner.chunk.c.hq, owner.chunk.c.ca
+        dev = actions.device
+        lib = load()
+        bounds = [(k0, min(k0 + tbtt, t_total)) for k0 in range(0, t_total, tbtt)]
+        nchunks = len(bounds)
+        (side,) = _side_streams(dev, 1)
+
+        actions_t = actions.transpose(0, 1).contiguous()                    # [T, B, 1, N]
+        states_t0 = states[:, :tau].transpose(0, 1).contiguous()            # [tau, B, 1, N]
+        lactions_t = torch.empty((t_total, b, ca, hq), device=dev, dtype=torch.float32)
+        fork = _Fork(side)
+        with fork:   # all T action encodings in one launch, beside the chunk-0 state encoding
+            _check(lib.sur_encoder_forward(_stream(), ctypes.byref(owner.action_enc.c), _p(actions_t), t_total * b,
+                                           _p(lactions_t)))
+        lstates = [torch.empty((tau, b, cs, hq), device=dev, dtype=torch.float32)]
+        _check(lib.sur_encoder_forward(_stream(), ctypes.byref(owner.state_enc.c), _p(states_t0), tau * b, _p(lstates[0])))
+        fork.join()
+
+        tm = surrogate.transition_model
+        h0 = tm.H0.unsqueeze(0).expand(b, -1, -1).contiguous()
+        c0 = tm.C0.unsqueeze(0).expand(b, -1, -1).contiguous()
+        seeds, h0s, c0s, h_alls, c_alls = [states_t0], [h0], [c0], [], []
+        d_all = torch.empty((t_total, b, 1, n), device=dev, dtype=torch.float32)
+        out_all = torch.empty_like(d_all)
+        for c, (k0, k1) in enumerate(bounds):
+            if c > 0:   # later chunks restart from the previous chunk's last prediction (gradients cut)
+                seeds.append(out_all[k0 - 1:k0])
+                lst = torch.empty((1, b, cs, hq), device=dev, dtype=torch.float32)
+                _check(lib.sur_encoder_forward(_stream(), ctypes.byref(owner.state_enc.c), _p(seeds[c]), b, _p(lst)))
+                lstates.append(lst)
+                h0s.append(h_alls[-1][-1])
+                c0s.append(c_alls[-1][-1])
+            k = k1 - k0
+            h_all = torch.empty((k, b, cs, hq), device=dev, dtype=torch.float32)
+            c_all = torch.empty_like(h_all)
+            s_used = min(seeds[c].shape[0], k)
+            _check(lib.sur_chunk_forward(_stream(), ctypes.byref(owner.chunk.c), _p(lactions_t[k0:k1]), _p(lstates[c]),
+                                         _p(seeds[c]), _p(h0s[c]), _p(c0s[c]), k, s_used, b, _p(h_all), _p(c_all),
+                                         _p(d_all[k0:k1]), _p(out_all[k0:k1])))
+            h_alls.append(h_all)
+            c_alls.append(c_all)
+        ctx.owner, ctx.bounds, ctx.dims = owner, bounds, (b, t_total, n, nchunks)
+        ctx.saved = (actions_t, lactions_t, seeds, lstates, h0s, c0s, h_alls, c_alls)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(out_all)
+        return d_all, out_all, h_alls[-1][-1], c_alls[-1][-1]
+
+    @staticmethod
+    def backward(ctx, dd_all, _dout, _dh, _dc):
+        owner, bounds = ctx.owner, ctx.bounds
+        b, t_total, n, nchunks = ctx.dims
+        actions_t, lactions_t, seeds, lstates, h0s, c0s, h_alls, c_alls = ctx.saved
+        lib = load()
+        dev = actions_t.device
+        if dd_all is None:
+            return (None,) * 7
+        dd_all = dd_all.contiguous()
+        dxlat_all = torch.empty_like(lactions_t)
+        owner.chunk.ensure_rows(nchunks * b)
+        enc_rows = [min(ENCODER_ROWS, ls.shape[0] * b) for ls in lstates]
+        owner.state_enc.ensure_rows(sum(enc_rows))
+        owner.refresh_partials()
+        streams = _side_streams(dev, nchunks)
+        forks, row0 = [], 0
+        for c, (k0, k1) in enumerate(bounds):
+            fork = _Fork(streams[c])
+            with fork:
+                dlst = torch.empty_like(lstates[c])
+                _check(lib.sur_chunk_backward(_stream(), ctypes.byref(owner.chunk.c), _p(lactions_t[k0:k1]), _p(lstates[c]),
+                                              _p(h0s[c]), _p(c0s[c]), _p(h_alls[c]), _p(c_alls[c]), _p(dd_all[k0:k1]), None,
+                                              None, None, k1 - k0, min(seeds[c].shape[0], k1 - k0), b,
+                                              _p(dxlat_all[k0:k1]), _p(dlst), None, None, c * b))
+                m = lstates[c].shape[0] * b
+                _check(lib.sur_encoder_backward(_stream(), ctypes.byref(owner.state_enc.c), _p(seeds[c]), _p(dlst), m, None,
+                                                row0, enc_rows[c]))
+                dlst.record_stream(streams[c])
+            row0 += enc_rows[c]
+            forks.append(fork)
+        for fork in forks:
+            fork.join()
+        _check(lib.sur_encoder_backward(_stream(), ctypes.byref(owner.action_enc.c), _p(actions_t), _p(dxlat_all),
+                                        t_total * b, None, 0, min(ENCODER_ROWS, owner.action_enc.c.rows)))
+        for pack in owner.packs:
+            pack.dirty = True
+        owner.schedule_flush()
+        return (None,) * 7
+
+
+def fused_tbptt(surrogate, states, actions, tau, tbtt):
+    """TBPTT forward of PDETrainingModule (training.py:71-98) on the fused kernels.  Returns
+    (outputs [B,T,1,N], outdeltas [B,T,1,N], (H, C)) with one action per step (the training layout)."""
+    b, _, _, n = states.shape
+    owner = packs_for(surrogate, n, b)
+    d_all, out_all, h, c = _TBPTTFn.apply(states, actions, owner.anchor, owner, surrogate, tau, tbtt)
+    return out_all.transpose(0, 1), d_all.transpose(0, 1), (h, c)

@@ -53,6 +53,12 @@ class PDETrainingModule(pl.LightningModule):
     def tbptt_forward(self, states, actions):
         """Chunks of ``tbtt`` steps; chunk 0 warms up on the first ``tau`` true states, later chunks
         start from the previous chunk's last prediction with gradients cut (state and hidden)."""
+        from pdecontrol.surrogates import ops
+        if ops.use_fused(states) and isinstance(self.surrogate, AutoRegPDESurrogate):
+            # every chunk in a handful of launches, independent work on parallel streams (hipops._TBPTTFn)
+            from pdecontrol.surrogates import hipops
+            outputs, deltas, hidden = hipops.fused_tbptt(self.surrogate, states, actions, self.tau, self.tbtt)
+            return [ModelRollout(outputs=outputs, deltas=deltas, hidden=tuple(h.detach() for h in hidden))]
         rollouts = []
         seed_states, hidden = None, None
         if isinstance(self.surrogate, AutoRegPDESurrogate):
