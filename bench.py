@@ -78,6 +78,40 @@ def cpu_baseline(E, N, L, target_seconds=12.0):
                       f"sub-steps, N={N}, OpenMP over envs, {dt:.1f} s"}
 
 
+def measure_secondary(kspde, local_rank, dev, name, mode, steps=20, warmup=3):
+    """Same measurement as the headline one for another BASELINE config (single GPU, events on the launch stream)."""
+    E, N, L = WORKLOADS[name]
+    stepper = kspde.KSStepper(E, N, L, DT, device=local_rank, mode=mode)
+    stream = torch.cuda.Stream(device=dev)
+    stepper.set_stream(stream.cuda_stream)
+    stepper.set_forcing(forcing_matrix(L, N))
+    stepper.set_state(np.stack([np.random.RandomState(1234 + e).uniform(-0.4, 0.4, N) for e in range(E)]))
+    for _ in range(4):
+        stepper.step(None, CFG_STEPS, want_obs=False)
+    acts = torch.from_numpy(np.random.RandomState(7).uniform(-1, 1, (steps + warmup, E, 4)).astype(np.float32)).to(dev)
+    d_obs = torch.empty((E, N), dtype=torch.float32, device=dev)
+    d_ssq = torch.empty(E, dtype=torch.float64, device=dev)
+    d_st = torch.zeros(E, dtype=torch.int32, device=dev)
+    with torch.cuda.stream(stream):
+        ev = []
+        for i in range(steps + warmup):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(stream)
+            stepper.step_device(d_actions=acts[i].data_ptr(), n_substeps=CFG_STEPS, d_obs=d_obs.data_ptr(),
+                                d_ssq=d_ssq.data_ptr(), d_status=d_st.data_ptr())
+            b.record(stream)
+            ev.append((a, b))
+    torch.cuda.synchronize(dev)
+    assert int(d_st.sum()) == 0
+    ms = float(np.mean([a.elapsed_time(b) for a, b in ev[warmup:]]))
+    gbs = 20.0 * N * E * CFG_STEPS / (ms * 1e-3) / 1e9
+    tf = FLOPS_PER_POINT_SUBSTEP * N * E * CFG_STEPS / (ms * 1e-3) / 1e12
+    return {"workload": f"KS L={L:g} N={N}, {E} envs (BASELINE.json configs[2])", "value": E * CFG_STEPS / (ms * 1e-3),
+            "unit": "sub-steps/s", "avg_launch_ms": ms, "kernel": stepper.layout(),
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                         "fp64_valu_frac": tf / FP64_PEAK_TFLOPS}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -210,6 +244,12 @@ def main():
                           "flops_per_point_substep": FLOPS_PER_POINT_SUBSTEP},
         },
     }
+    if rank == 0 and n_gpus == 1 and args.workload == "c2":
+        # secondary workload in the same run: BASELINE configs[2] (4096 x 256, L = 88) -- not the headline value
+        try:
+            out["workload_c3"] = measure_secondary(kspde, local_rank, dev, "c3", args.mode)
+        except Exception as exc:
+            out["workload_c3"] = {"error": f"{type(exc).__name__}: {exc}"}
     if rank == 0 and n_gpus == 1:
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(E, N, L)

@@ -888,7 +888,9 @@ chunk_bwd_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, con
             L.c[i] = (k > 0) ? c_all[prev] : c0[(size_t)b * s + i];
         }
         __syncthreads();
+        STAMP(20);
         step_forward_body(p, L, w);
+        STAMP(21);
 
         // ---- total gradient wrt d_k: direct + through out_k = base + delta*(d*mul + add) ----
         for (int i = threadIdx.x; i < n; i += blockDim.x) {
@@ -898,6 +900,7 @@ chunk_bwd_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, con
             L.dout_carry[i] = (k >= S) ? go : 0.0f;
         }
         __syncthreads();
+        STAMP(22);
         // ---- decoder backward ----
         conv_bwd_weight<5>(L.gA, 1, L.a2, 1, n, 1, 2, g[SUR_ST_CV3_W], g[SUR_ST_CV3_B], all_waves(), false);
         conv_bwd_data<5>(L.gA, 1, n, w[SUR_ST_CV3_W], 1, 1, 2, L.gB, false);
@@ -911,6 +914,7 @@ chunk_bwd_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, con
         deconv_bwd_weight(L.gA, p.cs, L.hnew, p.cs, p.hq, g[SUR_ST_DC0_W], g[SUR_ST_DC0_B], lower_half(), false);
         deconv_bwd_data(L.gA, p.cs, p.hq, w[SUR_ST_DC0_W], p.cs, L.dh, upper_half(), true);
 
+        STAMP(23);
         // ---- cell backward ----
         for (int i = threadIdx.x; i < s; i += blockDim.x) {
             const float dhn = L.dh[i] + L.dh_carry[i] + (dh_all ? dh_all[kb * s + i] : 0.0f);
@@ -924,6 +928,7 @@ chunk_bwd_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, con
             L.dc_carry[i] = dcn * gf;  // gradient wrt c_{k-1}
         }
         __syncthreads();
+        STAMP(24);
         {
             // four independent GEMMs on the gate gradients dG [4*cs][hq], issued without barriers in between:
             //   dx  [ca][hq]  = sum_g Wx_g^T * dG_g     (waves: first quarter)
@@ -995,6 +1000,7 @@ chunk_bwd_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, con
             }
             __syncthreads();
         }
+        STAMP(25);
         if (dxlat_t)
             for (int i = threadIdx.x; i < nx; i += blockDim.x) dxlat_t[kb * nx + i] = L.dx[i];
         for (int i = threadIdx.x; i < s; i += blockDim.x) {

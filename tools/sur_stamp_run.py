@@ -18,19 +18,27 @@ lib = hipops.load()
 lib.sur_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
 m = build_module(dev)
 batch = synthetic_batch(B=64, device=dev)
-with torch.no_grad():
-    m.training_step(batch, 0)
+def fwd_bwd():
+    for p in m.surrogate.parameters():
+        if p.grad is not None:
+            p.grad.zero_()
+    out = m.training_step(batch, 0)
+    out["loss"].backward()
     torch.cuda.synchronize()
-    lib.sur_debug_stamps(None, 1)
-    m.training_step(batch, 0)
-    torch.cuda.synchronize()
+
+
+fwd_bwd()
+lib.sur_debug_stamps(None, 1)
+fwd_bwd()
 buf = (ctypes.c_longlong * 32)()
 lib.sur_debug_stamps(buf, 0)
-names = ["(gap)", "gates gemm x8", "gate activations", "deconv0", "LN0+silu", "deconv1", "LN1+silu", "conv7", "LN2+silu",
-         "conv5", "step input load", "step output store"]
-vals = list(buf)[:12]
-tot = sum(vals[1:])
-print("20 steps, workgroup 0, cycles (shader clock):")
-for n, v in zip(names, vals):
-    print(f"  {n:22s} {v:10d}  {100.0 * v / max(tot, 1):5.1f}%   per step {v / 20:9.0f}")
-print("total per step", tot / 20)
+names = {1: "fwd gates gemm", 2: "fwd gate activations", 3: "fwd deconv0", 4: "fwd LN0+silu", 5: "fwd deconv1",
+         6: "fwd LN1+silu", 7: "fwd conv7", 8: "fwd LN2+silu", 9: "fwd conv5", 11: "fwd step output store",
+         21: "bwd: recompute forward (incl. the fwd phases above)", 22: "bwd: dd assembly", 23: "bwd: decoder backward",
+         24: "bwd: cell elementwise", 25: "bwd: cell GEMMs (dx, dh, gWx, gWh)"}
+vals = list(buf)
+print("one training step (forward + backward), workgroup 0, shader-clock cycles per rollout step:")
+print("(phases 1-9 accumulate over BOTH chunk_fwd and the recompute inside chunk_bwd: 40 executions)")
+for i, n in names.items():
+    per = vals[i] / (40 if i <= 9 else 20)
+    print(f"  {n:55s} {per:9.0f}")
