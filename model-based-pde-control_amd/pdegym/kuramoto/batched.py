@@ -136,5 +136,35 @@ class KSBatchedVecEnv(gym.vector.VectorEnv):
             obs[done] = self._fresh_rows(done).reshape(len(done), 1, self.N)
         return obs, rewards, terminated, truncated, infos
 
+    # -- device-resident stepping (no PCIe on the hot path) -----------------------------------
+    def step_torch(self, actions):
+        """``step`` for agents that live on the same GPU: ``actions`` is a CUDA fp32 tensor ``[E, 1, 4]``
+        (or ``[E, 4]``); returns ``(obs [E,1,N] fp32, rewards [E] fp64, truncated [E] bool)`` as CUDA
+        tensors written by the kernel, asynchronously on torch's current stream.  Episode bookkeeping
+        (timestep / truncation) stays on the host; autoreset is the caller's job (``reset_rows``)."""
+        import torch
+        assert actions.is_cuda and actions.dtype == torch.float32
+        a = actions.reshape(self.num_envs, -1).contiguous()
+        dev = a.device
+        if getattr(self, "_dev_out", None) is None or self._dev_out[0].device != dev:
+            self._dev_out = (torch.empty((self.num_envs, 1, self.N), dtype=torch.float32, device=dev),
+                             torch.empty(self.num_envs, dtype=torch.float64, device=dev),
+                             torch.zeros(self.num_envs, dtype=torch.int32, device=dev))
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        if getattr(self, "_stream_handle", None) != stream:
+            self.stepper.set_stream(stream)
+            self._stream_handle = stream
+        obs, ssq, status = self._dev_out
+        self.stepper.step_device(d_actions=a.data_ptr(), n_substeps=self.cfg_steps, d_obs=obs.data_ptr(),
+                                 d_ssq=ssq.data_ptr(), d_status=status.data_ptr())
+        rewards = ssq * (-(1.0 / self.N) / self.cfg_steps)
+        self.timestep += 1
+        truncated = torch.from_numpy(self.timestep >= self.max_episode_steps).to(dev, non_blocking=True)
+        return obs, rewards, truncated, status
+
+    def reset_rows(self, ids):
+        """Fresh IC + burn-in for the listed envs (the autoreset of ``step_wait`` as an explicit call)."""
+        return self._fresh_rows(np.asarray(ids, dtype=np.int32))
+
     def close_extras(self, **kwargs):
         self.stepper.close()

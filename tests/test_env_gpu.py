@@ -89,3 +89,21 @@ def test_vec_env_large_batch_runs(api):
     o, r, term, trunc, infos = vec.step(np.random.RandomState(1).uniform(-1, 1, (1024, 1, 4)).astype(np.float32))
     assert o.shape == (1024, 1, 64) and np.isfinite(o).all() and (r < 0).all()
     assert vec.stepper.layout()["variant"] in ("wave64_dpp", "row16_dpp")
+
+
+def test_vec_env_device_resident_step(api):
+    import torch
+    _, make_vec = api
+    E = 64
+    a_host = np.random.RandomState(2).uniform(-1, 1, (E, 1, 4)).astype(np.float32)
+    ref = make_vec(E, burn_in=False)
+    ref.reset(seed=7)
+    o_ref, r_ref, _, _, _ = ref.step(a_host)
+    dev_env = make_vec(E, burn_in=False)
+    dev_env.reset(seed=7)
+    obs, rew, trunc, status = dev_env.step_torch(torch.from_numpy(a_host).cuda())
+    torch.cuda.synchronize()
+    assert obs.is_cuda and obs.shape == (E, 1, 64) and rew.dtype == torch.float64
+    np.testing.assert_array_equal(obs.cpu().numpy(), o_ref)
+    np.testing.assert_allclose(rew.cpu().numpy(), r_ref, rtol=1e-14)
+    assert not trunc.any() and int(status.sum()) == 0
