@@ -73,6 +73,30 @@ def time_graphed(device, batch, steps, warmup):
             "loss_after_training": float(graphed.result["loss"].detach())}
 
 
+def time_ensemble(device, members, steps, warmup, B=64):
+    """``members`` independently seeded surrogates (the reference's ensemble, mbrl.py:109) stepping side by
+    side on one GPU, each on its own batch of B sequences."""
+    from pdecontrol.surrogates.ensemble_step import EnsembleTBPTTStep
+    modules = [build_module(device, seed=i) for i in range(members)]
+    batches = []
+    for i in range(members):
+        g = torch.Generator().manual_seed(50 + i)
+        batches.append(((torch.rand(B, 20, 1, 64, generator=g) * 2 - 1).to(device),
+                        (torch.rand(B, 20, 1, 64, generator=g) * 2 - 1).to(device)))
+    ens = EnsembleTBPTTStep(modules, tuple(batches[0][0].shape))
+    ens.step(batches)
+    for _ in range(warmup):
+        ens.step()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ens.step()
+    torch.cuda.synchronize(device)
+    dt = (time.perf_counter() - t0) / steps
+    return {"members": members, "value": members * B / dt, "ms_per_step": dt * 1e3, "steps": steps,
+            "losses": [float(r["loss"].detach()) for r in ens.step()]}
+
+
 def run(device, steps=50, warmup=5, B=64, cpu_steps=3):
     batch = synthetic_batch(B=B, device=device)
     res = {"unit": "seqs/s", "config": {"factory": "KSAutoRegConvolutionalLSTM", "B": B, "T": 20, "tau": 5,
@@ -90,6 +114,8 @@ def run(device, steps=50, warmup=5, B=64, cpu_steps=3):
         ops.enable_fused(True)
         res["hip_graph_fused"] = time_graphed(device, batch, steps * 4, warmup)
         loss_fused = first_loss(device, B)
+        # the reference's default ensemble (3 members, script.py:60) and a 4-member one, stepped side by side
+        res["ensemble"] = [time_ensemble(device, m, steps * 2, warmup, B) for m in (3, 4)]
     finally:
         ops.enable_fused(False)
     res["value"] = res["hip_graph_fused"]["value"]

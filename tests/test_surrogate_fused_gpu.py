@@ -169,3 +169,39 @@ def test_fused_hip_graph_training_matches_unfused(dev):
         ops.enable_fused(False)
     np.testing.assert_allclose(l_fused, l_plain, rtol=3e-5)
     assert l_fused[-1] < l_fused[0]
+
+
+def test_ensemble_parallel_step_equals_member_by_member(dev):
+    """Three ensemble members stepped side by side on their own streams == stepped one after the other
+    (the reference's order, mbrl.py:408): same graphs, deterministic reductions -> bit-identical."""
+    from pdecontrol.surrogates import ops
+    from pdecontrol.surrogates.bench_tbptt import build_module, synthetic_batch
+    from pdecontrol.surrogates.ensemble_step import EnsembleTBPTTStep
+    from pdecontrol.surrogates.graph_step import GraphedTBPTTStep
+    batches = []
+    for i in range(3):
+        s, a = synthetic_batch(B=16, device=dev)
+        batches.append((s.roll(i, 0) * (1 - 0.1 * i), a.roll(i, 1)))
+    try:
+        ops.enable_fused(True)
+        seq_losses, seq_params = [], []
+        for i in range(3):
+            g = GraphedTBPTTStep(build_module(dev, seed=i), tuple(batches[i][0].shape))
+            g.step(*batches[i])
+            seq_losses.append([float(g.step()["loss"].detach()) for _ in range(3)])
+            seq_params.append(torch.cat([p.detach().reshape(-1) for p in g.module.surrogate.parameters()]).clone())
+        ens = EnsembleTBPTTStep([build_module(dev, seed=i) for i in range(3)], tuple(batches[0][0].shape))
+        ens.step(batches)
+        ens_losses = [[] for _ in range(3)]
+        for _ in range(3):
+            res = ens.step()
+            torch.cuda.synchronize(dev)
+            for i, r in enumerate(res):
+                ens_losses[i].append(float(r["loss"].detach()))
+        for i, g in enumerate(ens.members):
+            flat = torch.cat([p.detach().reshape(-1) for p in g.module.surrogate.parameters()])
+            assert torch.equal(flat, seq_params[i]), f"member {i} parameters differ"
+        assert ens_losses == seq_losses
+        assert len({l[0] for l in ens_losses}) == 3  # members really are different models / batches
+    finally:
+        ops.enable_fused(False)
