@@ -4,14 +4,23 @@ The reference updates its ensemble one member after the other (pdecontrol/mbrl/m
 comprehension over ``update_surrogate(module, trainer)``; 3 members by default, script.py:60), each on
 its own bootstrapped batches.  On an MI355X one member's fused step is 64 workgroups (one per sequence)
 on a 256-CU device and bound by the dependent-phase latency inside each workgroup, so the members do
-not compete for anything: every member's captured step graph is replayed on its own HIP stream and the
-hardware runs them side by side.  Results are bit-identical to stepping the members in turn (same
-graphs, same kernels, deterministic gradient reduction).
+not compete for anything: all members' steps are recorded as sibling branches of ONE hipGraph (each
+member on its own stream forked from the capture stream, joined at the end) and the hardware runs them
+side by side.
+
+Constructions that do NOT work on ROCm 7 (measured, so nobody retries them): one graph per member
+replayed on separate streams serialises; member graphs as child-graph nodes of a parent graph serialise
+too (and lose the overlap inside a member); forked streams that fork again crash hipStreamEndCapture
+(tools/dbg_capture.py) -- hence ``inner_forks(False)``: inside the ensemble graph a member keeps its own
+step on one stream and the parallelism comes from the members.
+
+Results are bit-identical to stepping the members in turn (same kernels, deterministic reductions).
 """
 from typing import Sequence
 
 import torch
 
+from pdecontrol.surrogates import hipops
 from pdecontrol.surrogates.graph_step import GraphedTBPTTStep
 
 
@@ -19,10 +28,24 @@ class EnsembleTBPTTStep:
     def __init__(self, modules: Sequence, batch_shape, action_shape=None, lr=None, warmup=3):
         """modules: PDETrainingModules on ONE CUDA device (distinct parameters); batch_shape: [B, T, 1, N]."""
         assert len(modules) > 0
-        self.members = [GraphedTBPTTStep(m, batch_shape, action_shape, lr=lr, warmup=warmup) for m in modules]
-        self.device = self.members[0].device
-        assert all(g.device == self.device for g in self.members), "ensemble members must share one GPU"
-        self.streams = [torch.cuda.Stream(device=self.device) for _ in self.members]
+        with hipops.inner_forks(False):
+            self.members = [GraphedTBPTTStep(m, batch_shape, action_shape, lr=lr, warmup=warmup, capture=False)
+                            for m in modules]
+            self.device = self.members[0].device
+            assert all(g.device == self.device for g in self.members), "ensemble members must share one GPU"
+            # member 0 stays on the capture stream, the others are its siblings
+            self.streams = [torch.cuda.Stream(device=self.device) for _ in self.members[1:]]
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                cur = torch.cuda.current_stream(self.device)
+                for st in self.streams:
+                    st.wait_stream(cur)                      # fork
+                for g, st in zip(self.members, [cur] + self.streams):
+                    with torch.cuda.stream(st):
+                        g.result = g._fwd_bwd()
+                        g.opt.step()
+                for st in self.streams:
+                    cur.wait_stream(st)                      # join
 
     def __len__(self):
         return len(self.members)
@@ -35,15 +58,9 @@ class EnsembleTBPTTStep:
             g.actions.copy_(a, non_blocking=True)
 
     def step(self, batches=None):
-        """One optimizer step of every member, concurrently.  Returns the members' static result dicts;
-        the caller's current stream waits for all of them."""
-        cur = torch.cuda.current_stream(self.device)
+        """One optimizer step of every member, concurrently.  Returns the members' static result dicts
+        (overwritten by the next step)."""
         if batches is not None:
             self.load(batches)
-        for g, st in zip(self.members, self.streams):
-            st.wait_stream(cur)
-            with torch.cuda.stream(st):
-                g.g_main.replay()
-        for st in self.streams:
-            cur.wait_stream(st)
+        self.graph.replay()
         return [g.result for g in self.members]

@@ -15,8 +15,10 @@ from pdecontrol.surrogates.distributed import FlatGradBucket
 
 
 class GraphedTBPTTStep:
-    def __init__(self, module, batch_shape, action_shape=None, lr=None, distributed=False, warmup=3):
-        """module: PDETrainingModule on a CUDA device; batch_shape: [B, T, 1, N] of states."""
+    def __init__(self, module, batch_shape, action_shape=None, lr=None, distributed=False, warmup=3, capture=True):
+        """module: PDETrainingModule on a CUDA device; batch_shape: [B, T, 1, N] of states.
+        capture=False prepares everything (static buffers, warmed-up kernels, fresh Adam state) but leaves
+        the capture to the caller (EnsembleTBPTTStep records several members into one graph)."""
         self.module = module
         dev = next(module.surrogate.parameters()).device
         assert dev.type == "cuda", "HIP graphs need the module on a GPU"
@@ -28,7 +30,10 @@ class GraphedTBPTTStep:
         self.lr = lr if lr is not None else module.lr
         self.opt = self._make_adam()
         self.result = None
-        self._capture(warmup)
+        self.g_main = self.g_opt = None
+        self._prepare(warmup)
+        if capture:
+            self._capture()
 
     def _make_adam(self):
         """Adam as ONE multi-tensor kernel (fused=True) instead of ~3 tiny kernels per parameter."""
@@ -44,7 +49,7 @@ class GraphedTBPTTStep:
         out["loss"].backward()
         return out
 
-    def _capture(self, warmup):
+    def _prepare(self, warmup):
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         # warm-up on a side stream with the real optimizer state untouched: snapshot and restore
@@ -69,6 +74,8 @@ class GraphedTBPTTStep:
                 st["exp_avg"].zero_()
                 st["exp_avg_sq"].zero_()
         torch.cuda.synchronize(self.device)
+
+    def _capture(self):
         self.g_main = torch.cuda.CUDAGraph()
         if not self.distributed:
             with torch.cuda.graph(self.g_main):

@@ -210,6 +210,7 @@ class FusedPacks:
         self.anchor = torch.zeros((), device=dev, requires_grad=True)
         self.key = self._key(surrogate, n)
         self._flush_queued = False
+        self.side_streams = []
 
     @staticmethod
     def _key(surrogate, n):
@@ -359,27 +360,49 @@ def fused_rollout(surrogate, states, actions, times, targets, hidden):
 # ---------------------------------------------------------------------------------------------
 # whole TBPTT forward/backward as ONE autograd node with hand-scheduled streams
 # ---------------------------------------------------------------------------------------------
-_SIDE_STREAMS = {}
-
-
-def _side_streams(device, n):
-    pool = _SIDE_STREAMS.setdefault(device, [])
+def _side_streams(owner, device, n):
+    """Side streams are owned by the surrogate's FusedPacks: two surrogates stepping concurrently (ensemble
+    members captured as parallel graph branches) must not meet on a shared stream."""
+    pool = owner.side_streams
     while len(pool) < n:
         pool.append(torch.cuda.Stream(device=device))
     return pool[:n]
 
 
+_INNER_FORKS = True
+
+
+class inner_forks:
+    """``with inner_forks(False): ...`` -- the fused TBPTT step stays on the current stream instead of forking
+    side streams.  Needed when the step itself runs on a forked stream of a hipGraph capture: a forked stream
+    that forks again crashes hipStreamEndCapture on ROCm 7 (tools/dbg_capture.py)."""
+
+    def __init__(self, enabled):
+        self.enabled = bool(enabled)
+
+    def __enter__(self):
+        global _INNER_FORKS
+        self.prev, _INNER_FORKS = _INNER_FORKS, self.enabled
+        return self
+
+    def __exit__(self, *exc):
+        global _INNER_FORKS
+        _INNER_FORKS = self.prev
+
+
 class _Fork:
     """``with _Fork(stream): ...`` -- run the block on ``stream`` after everything queued so far on the
     current stream; ``join()`` makes the current stream wait for it.  Works eagerly and under hipGraph
-    capture (the side work becomes a parallel branch of the graph)."""
+    capture (the side work becomes a parallel branch of the graph).  With ``inner_forks(False)`` the block
+    simply runs on the current stream."""
 
     def __init__(self, stream):
-        self.stream = stream
         self.main = torch.cuda.current_stream(stream.device)
+        self.stream = stream if _INNER_FORKS else self.main
 
     def __enter__(self):
-        self.stream.wait_stream(self.main)
+        if self.stream is not self.main:
+            self.stream.wait_stream(self.main)
         self.ctx = torch.cuda.stream(self.stream)
         self.ctx.__enter__()
         return self
@@ -388,7 +411,8 @@ class _Fork:
         self.ctx.__exit__(*exc)
 
     def join(self):
-        self.main.wait_stream(self.stream)
+        if self.stream is not self.main:
+            self.main.wait_stream(self.stream)
 
 
 class _TBPTTFn(torch.autograd.Function):
@@ -408,7 +432,7 @@ class _TBPTTFn(torch.autograd.Function):
         lib = load()
         bounds = [(k0, min(k0 + tbtt, t_total)) for k0 in range(0, t_total, tbtt)]
         nchunks = len(bounds)
-        (side,) = _side_streams(dev, 1)
+        (side,) = _side_streams(owner, dev, 1)
 
         actions_t = actions.transpose(0, 1).contiguous()                    # [T, B, 1, N]
         states_t0 = states[:, :tau].transpose(0, 1).contiguous()            # [tau, B, 1, N]
@@ -465,7 +489,7 @@ class _TBPTTFn(torch.autograd.Function):
         enc_rows = [min(ENCODER_ROWS, ls.shape[0] * b) for ls in lstates]
         owner.state_enc.ensure_rows(sum(enc_rows))
         owner.refresh_partials()
-        streams = _side_streams(dev, nchunks)
+        streams = _side_streams(owner, dev, nchunks)
         forks, row0 = [], 0
         for c, (k0, k1) in enumerate(bounds):
             fork = _Fork(streams[c])
@@ -478,7 +502,7 @@ class _TBPTTFn(torch.autograd.Function):
                 m = lstates[c].shape[0] * b
                 _check(lib.sur_encoder_backward(_stream(), ctypes.byref(owner.state_enc.c), _p(seeds[c]), _p(dlst), m, None,
                                                 row0, enc_rows[c]))
-                dlst.record_stream(streams[c])
+                dlst.record_stream(fork.stream)
             row0 += enc_rows[c]
             forks.append(fork)
         for fork in forks:
