@@ -77,21 +77,42 @@ int sur_encoder_backward(void* stream, const sur_encoder_params* p, const float*
                          float* dx, int row_base, int row_count);
 int sur_flush_encoder_grads(void* stream, const sur_encoder_params* p);
 
+/* Floats per (step, sample) of the forward intermediates sur_chunk_forward can save for sur_chunk_backward
+ * (activated gates, c_k, h_k, decoder activations), or 0 if this geometry has no saved-activation path.
+ * With a `saved` buffer [K,B,sur_chunk_saved_floats] the backward kernel streams the intermediates back from
+ * HBM (prefetched one step ahead) instead of recomputing the step's forward: 12.8 KB per step and sample at
+ * N = 64 -- HBM capacity and bandwidth are free on this device, dependent-phase latency is not. */
+int sur_chunk_saved_floats(const sur_chunk_params* p);
+
 /* Time-major tensors: xlat_t [K,B,ca,hq]; lstates_t [S,B,cs,hq] (encoded given states, S >= 1);
  * states_t [S,B,1,N] (the given states: bases of the teacher-forced steps); h0, c0 [B,cs,hq].
  * Outputs: h_all, c_all [K,B,cs,hq]; d_all, out_all [K,B,1,N]. */
 int sur_chunk_forward(void* stream, const sur_chunk_params* p, const float* xlat_t, const float* lstates_t,
                       const float* states_t, const float* h0, const float* c0, int k, int s, int b, float* h_all,
-                      float* c_all, float* d_all, float* out_all);
+                      float* c_all, float* d_all, float* out_all, float* saved /* may be NULL */);
 /* Upstream gradients (each may be NULL = 0): dd_all / dout_all [K,B,1,N] wrt d_all / out_all;
  * dh_all / dc_all [K,B,cs,hq] wrt h_all / c_all.  Outputs (each may be NULL): dxlat_t [K,B,ca,hq],
  * dlstates_t [S,B,cs,hq], dh0, dc0 [B,cs,hq].  Accumulates parameter gradients into rows
- * [row_base, row_base + B) of p->partial. */
+ * [row_base, row_base + B) of p->partial.  Results are bit-identical with and without `saved`. */
 int sur_chunk_backward(void* stream, const sur_chunk_params* p, const float* xlat_t, const float* lstates_t,
                        const float* h0, const float* c0, const float* h_all, const float* c_all,
                        const float* dd_all, const float* dout_all, const float* dh_all, const float* dc_all, int k,
-                       int s, int b, float* dxlat_t, float* dlstates_t, float* dh0, float* dc0, int row_base);
+                       int s, int b, float* dxlat_t, float* dlstates_t, float* dh0, float* dc0, int row_base,
+                       const float* saved /* what sur_chunk_forward wrote, or NULL = recompute */);
 int sur_flush_chunk_grads(void* stream, const sur_chunk_params* p);
+
+/* Delta-mode TBPTT loss in one launch (reference: pdecontrol/surrogates/training.py:100-121):
+ *   deltas[b,t]  = ((states[b,t+1] - states[b,t]) / delta - mean) / stdv          t < T-1   (undscaling forward)
+ *   loss         = mean over (b, t < T-1, i) of (d_all[t,b,i] - deltas[b,t,i])^2  (MSE, reduction "none" + mean)
+ *   hsteploss[t] = the same mean per time step;  stats = {mean, unbiased std} of the predicted deltas
+ *                  d_all[:T-1], then of the true deltas (the four "Train ... Delta" metrics)
+ *   dd_all       = d loss / d d_all  [T,B,1,N] (last step zero), may be NULL
+ * states [B,T,1,N]; d_all [T,B,1,N] time-major as written by sur_chunk_forward; deltas [B,T-1,1,N];
+ * hsteploss [T-1]; loss [1]; stats [4]; partial: scratch of 5*T doubles; ticket: one zero-initialised
+ * unsigned the kernel leaves at zero.  Sums are fp64 and reduced in a fixed order (deterministic). */
+int sur_tbptt_delta_loss(void* stream, const float* states, const float* d_all, int b, int t, int n, float delta, float mean,
+                         float stdv, float* deltas, float* dd_all, float* hsteploss, float* loss, float* stats,
+                         double* partial, unsigned int* ticket);
 
 const char* sur_last_error(void);
 

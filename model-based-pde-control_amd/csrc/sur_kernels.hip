@@ -694,6 +694,85 @@ __global__ void __launch_bounds__(TPB) enc_bwd_kernel(const sur_encoder_params p
 }
 
 // ---------------------------------------------------------------------------------------------
+// TBPTT delta-mode loss: one launch for what the reference spells as ~30 tiny torch ops
+// (pdecontrol/surrogates/training.py:100-121): true deltas from the state sequence, the undscaling
+// forward, the element-wise MSE, its time-resolved and overall means, the four logged statistics and
+// the gradient of the mean loss wrt the predicted deltas.
+//   grid = T workgroups: workgroup t < T-1 handles time step t of all samples, workgroup T-1 only zeroes
+//   the (unused) last step's gradient.  Partial sums are fp64 and reduced in a fixed order by the
+//   workgroup that arrives last (ticket counter), so the result does not depend on scheduling.
+// ---------------------------------------------------------------------------------------------
+constexpr int LOSS_NSUM = 5;  // squared error, sum / sum of squares of predicted deltas, same of true deltas
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+__global__ void __launch_bounds__(TPB)
+delta_loss_kernel(const float* __restrict__ states, const float* __restrict__ d_all, int B, int T, int N, float delta,
+                  float mean, float stdv, float* __restrict__ deltas, float* __restrict__ dd_all,
+                  float* __restrict__ hsteploss, float* __restrict__ loss, float* __restrict__ stats,
+                  double* __restrict__ partial, unsigned int* __restrict__ ticket) {
+    __shared__ double red[TPB / 64][LOSS_NSUM];
+    __shared__ bool last;
+    const int t = blockIdx.x, per_t = B * N;
+    const double count = (double)per_t * (T - 1);
+    double acc[LOSS_NSUM] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    if (t < T - 1) {
+        const float gscale = (float)(2.0 / count);
+        for (int e = threadIdx.x; e < per_t; e += blockDim.x) {
+            const int b = e / N, i = e - b * N;
+            const size_t sidx = ((size_t)b * T + t) * N + i;
+            const float dl = ((states[sidx + N] - states[sidx]) / delta - mean) / stdv;
+            const float od = d_all[((size_t)t * B + b) * N + i];
+            deltas[((size_t)b * (T - 1) + t) * N + i] = dl;
+            const float err = od - dl;
+            if (dd_all) dd_all[((size_t)t * B + b) * N + i] = gscale * err;
+            acc[0] += (double)(err * err);
+            acc[1] += od;
+            acc[2] += (double)od * od;
+            acc[3] += dl;
+            acc[4] += (double)dl * dl;
+        }
+    } else if (dd_all) {
+        for (int e = threadIdx.x; e < per_t; e += blockDim.x) dd_all[(size_t)t * per_t + e] = 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < LOSS_NSUM; ++j) {
+        const double w = wave_sum(acc[j]);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][j] = w;
+    }
+    __syncthreads();
+    if (threadIdx.x < LOSS_NSUM) {
+        double v = 0.0;
+        for (int w = 0; w < TPB / 64; ++w) v += red[w][threadIdx.x];
+        partial[(size_t)t * LOSS_NSUM + threadIdx.x] = v;
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) last = (atomicAdd(ticket, 1u) == (unsigned)(gridDim.x - 1));
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    const volatile double* part = partial;
+    for (int tt = threadIdx.x; tt < T - 1; tt += blockDim.x) hsteploss[tt] = (float)(part[(size_t)tt * LOSS_NSUM] / per_t);
+    if (threadIdx.x == 0) {
+        double tot[LOSS_NSUM] = {0.0, 0.0, 0.0, 0.0, 0.0};
+        for (int tt = 0; tt < T - 1; ++tt)
+            for (int j = 0; j < LOSS_NSUM; ++j) tot[j] += part[(size_t)tt * LOSS_NSUM + j];
+        *loss = (float)(tot[0] / count);
+        const double m_od = tot[1] / count, m_dl = tot[3] / count;
+        stats[0] = (float)m_od;
+        stats[1] = (float)sqrt(fmax(tot[2] - count * m_od * m_od, 0.0) / (count - 1.0));  // unbiased, like Tensor.std()
+        stats[2] = (float)m_dl;
+        stats[3] = (float)sqrt(fmax(tot[4] - count * m_dl * m_dl, 0.0) / (count - 1.0));
+        *ticket = 0u;  // ready for the next launch (graph replay)
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // TBPTT chunk: K x (ConvLSTM cell + decoder + integration), time loop inside the kernel
 // ---------------------------------------------------------------------------------------------
 struct StepLayout {
@@ -715,6 +794,14 @@ __host__ __device__ inline int step_act_floats(const sur_chunk_params& p, bool b
     if (backward) total += 4 * s + s + 3 * step_max_act(p) + p.ca * p.hq + s + 2 * s + n;
     return total;
 }
+
+// Floats of one step's forward intermediates as the forward kernel can save them for the backward kernel:
+// the LDS block [gates .. a2] (activated gates, c_k, h_k, decoder pre-/post-LayerNorm activations).
+__host__ __device__ inline int step_saved_floats(const sur_chunk_params& p) {
+    const int s = p.cs * p.hq, n = 4 * p.hq;
+    return 6 * s + 2 * p.cs * 2 * p.hq + 2 * p.c_mid * n + 2 * n;
+}
+constexpr int SAVED_MAX_V4 = 16;  // float4 registers per thread the backward kernel may prefetch into
 
 __device__ void step_layout(const sur_chunk_params& p, float* lds, bool backward, StepLayout& L) {
     const int s = p.cs * p.hq, n = 4 * p.hq;
@@ -813,10 +900,11 @@ __global__ void __launch_bounds__(TPB)
 chunk_fwd_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, const float* __restrict__ lstates_t,
                  const float* __restrict__ states_t, const float* __restrict__ h0, const float* __restrict__ c0, int K,
                  int S, int B, float* __restrict__ h_all, float* __restrict__ c_all, float* __restrict__ d_all,
-                 float* __restrict__ out_all) {
+                 float* __restrict__ out_all, float* __restrict__ saved) {
     extern __shared__ __align__(16) float lds[];
     StepLayout L;
     step_layout(p, lds, false, L);
+    const int nsave4 = step_saved_floats(p) >> 2;
     ParamViews<SUR_ST_NPARAM> v;
     stage_weights<SUR_ST_NPARAM>(p.w, p.size, L.end, v);
     const int b = blockIdx.x, s = p.cs * p.hq, nx = p.ca * p.hq, n = L.n;
@@ -838,6 +926,11 @@ chunk_fwd_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, con
         __syncthreads();
         STAMP(10);
         step_forward_body(p, L, v.w);
+        if (saved) {  // every intermediate the backward kernel needs: it then skips the recomputation
+            float4* dst = reinterpret_cast<float4*>(saved + kb * (size_t)(nsave4 << 2));
+            const float4* src = reinterpret_cast<const float4*>(L.gates);
+            for (int i = threadIdx.x; i < nsave4; i += blockDim.x) dst[i] = src[i];
+        }
         for (int i = threadIdx.x; i < s; i += blockDim.x) {
             h_all[kb * s + i] = L.hnew[i];
             c_all[kb * s + i] = L.cnew[i];
@@ -860,10 +953,23 @@ chunk_bwd_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, con
                  const float* __restrict__ c_all, const float* __restrict__ dd_all, const float* __restrict__ dout_all,
                  const float* __restrict__ dh_all, const float* __restrict__ dc_all, int K, int S, int B,
                  float* __restrict__ dxlat_t, float* __restrict__ dlstates_t, float* __restrict__ dh0,
-                 float* __restrict__ dc0, int grads_in_lds, int row_base) {
+                 float* __restrict__ dc0, int grads_in_lds, int row_base, const float* __restrict__ saved) {
     extern __shared__ __align__(16) float lds[];
     StepLayout L;
     step_layout(p, lds, true, L);
+    // Saved forward intermediates of step k travel HBM -> registers while step k+1 is being processed and
+    // are committed to LDS at the top of step k: the load latency is off the critical path.
+    const int nsave4 = step_saved_floats(p) >> 2;
+    float4 pre[SAVED_MAX_V4];
+    auto prefetch = [&](int k) {
+        const float4* src = reinterpret_cast<const float4*>(saved + ((size_t)k * B + blockIdx.x) * (size_t)(nsave4 << 2));
+#pragma unroll
+        for (int i = 0; i < SAVED_MAX_V4; ++i) {
+            const int idx = threadIdx.x + i * TPB;
+            if (idx < nsave4) pre[i] = src[idx];
+        }
+    };
+    if (saved) prefetch(K - 1);
     ParamViews<SUR_ST_NPARAM> v;
     stage_weights<SUR_ST_NPARAM>(p.w, p.size, L.end, v);
     const int psize = psize_of<SUR_ST_NPARAM>(p.size);
@@ -887,9 +993,21 @@ chunk_bwd_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, con
             L.h[i] = (k < S) ? lstates_t[kb * s + i] : (k > 0 ? h_all[prev] : h0[(size_t)b * s + i]);
             L.c[i] = (k > 0) ? c_all[prev] : c0[(size_t)b * s + i];
         }
+        if (saved) {
+            float4* dst = reinterpret_cast<float4*>(L.gates);
+#pragma unroll
+            for (int i = 0; i < SAVED_MAX_V4; ++i) {
+                const int idx = threadIdx.x + i * TPB;
+                if (idx < nsave4) dst[idx] = pre[i];
+            }
+        }
         __syncthreads();
         STAMP(20);
-        step_forward_body(p, L, w);
+        if (saved) {
+            if (k > 0) prefetch(k - 1);
+        } else {
+            step_forward_body(p, L, w);
+        }
         STAMP(21);
 
         // ---- total gradient wrt d_k: direct + through out_k = base + delta*(d*mul + add) ----
@@ -1128,28 +1246,40 @@ int sur_flush_encoder_grads(void* stream, const sur_encoder_params* p) {
     }, "flush_enc");
 }
 
+int sur_chunk_saved_floats(const sur_chunk_params* p) {
+    if (!p) return 0;
+    const int total = step_saved_floats(*p);
+    // float4 granularity of the block and of its LDS position; must fit the backward kernel's prefetch registers
+    if ((p->hq & 3) || ((p->ca * p->hq) & 3) || (total >> 2) > SAVED_MAX_V4 * TPB) return 0;
+    return total;
+}
+
 int sur_chunk_forward(void* stream, const sur_chunk_params* p, const float* xlat_t, const float* lstates_t,
                       const float* states_t, const float* h0, const float* c0, int k, int s, int b, float* h_all,
-                      float* c_all, float* d_all, float* out_all) {
+                      float* c_all, float* d_all, float* out_all, float* saved) {
     if (!p || !xlat_t || !h0 || !c0 || !h_all || !c_all || !d_all || !out_all || k <= 0 || b <= 0 || s < 1 ||
         !lstates_t || !states_t)
         return fail(-1, "sur_chunk_forward: bad argument (need K > 0, B > 0, S >= 1)");
     if (4 * p->hq > 64 * LN_MAX_EPL) return fail(-4, "sur_chunk_forward: N = %d too wide for the fused LayerNorm", 4 * p->hq);
     const int psize = psize_of<SUR_ST_NPARAM>(p->size);
     const size_t lds = sizeof(float) * (step_act_floats(*p, false) + psize);
+    if (saved && sur_chunk_saved_floats(p) == 0)
+        return fail(-4, "sur_chunk_forward: this geometry has no saved-activation path (pass saved = NULL)");
     if (int rc = set_lds(chunk_fwd_kernel, lds, "chunk forward")) return rc;
     return launch_checked([&] {
         hipLaunchKernelGGL(chunk_fwd_kernel, dim3(b), dim3(TPB), lds, (hipStream_t)stream, *p, xlat_t, lstates_t, states_t, h0,
-                           c0, k, s, b, h_all, c_all, d_all, out_all);
+                           c0, k, s, b, h_all, c_all, d_all, out_all, saved);
     }, "chunk_fwd");
 }
 
 int sur_chunk_backward(void* stream, const sur_chunk_params* p, const float* xlat_t, const float* lstates_t,
                        const float* h0, const float* c0, const float* h_all, const float* c_all, const float* dd_all,
                        const float* dout_all, const float* dh_all, const float* dc_all, int k, int s, int b,
-                       float* dxlat_t, float* dlstates_t, float* dh0, float* dc0, int row_base) {
+                       float* dxlat_t, float* dlstates_t, float* dh0, float* dc0, int row_base, const float* saved) {
     if (!p || !xlat_t || !lstates_t || !h0 || !c0 || !h_all || !c_all || k <= 0 || b <= 0 || s < 1)
         return fail(-1, "sur_chunk_backward: bad argument");
+    if (saved && sur_chunk_saved_floats(p) == 0)
+        return fail(-4, "sur_chunk_backward: this geometry has no saved-activation path (pass saved = NULL)");
     if (!p->partial || row_base < 0 || p->rows < row_base + b)
         return fail(-1, "sur_chunk_backward: partial gradient buffer has %d rows, need [%d, %d)", p->rows, row_base, row_base + b);
     const int psize = psize_of<SUR_ST_NPARAM>(p->size);
@@ -1159,7 +1289,8 @@ int sur_chunk_backward(void* stream, const sur_chunk_params* p, const float* xla
     if (int rc = set_lds(chunk_bwd_kernel, lds, "chunk backward")) return rc;
     return launch_checked([&] {
         hipLaunchKernelGGL(chunk_bwd_kernel, dim3(b), dim3(TPB), lds, (hipStream_t)stream, *p, xlat_t, lstates_t, h0, c0, h_all,
-                           c_all, dd_all, dout_all, dh_all, dc_all, k, s, b, dxlat_t, dlstates_t, dh0, dc0, grads_in_lds, row_base);
+                           c_all, dd_all, dout_all, dh_all, dc_all, k, s, b, dxlat_t, dlstates_t, dh0, dc0, grads_in_lds, row_base,
+                           saved);
     }, "chunk_bwd");
 }
 
@@ -1172,6 +1303,18 @@ int sur_flush_chunk_grads(void* stream, const sur_chunk_params* p) {
         hipLaunchKernelGGL((flush_grads_kernel<SUR_ST_NPARAM, sur_chunk_params>), dim3((psize + 31) / 32), dim3(TPB), 0,
                            (hipStream_t)stream, *p, psize);
     }, "flush_chunk");
+}
+
+int sur_tbptt_delta_loss(void* stream, const float* states, const float* d_all, int b, int t, int n, float delta, float mean,
+                         float stdv, float* deltas, float* dd_all, float* hsteploss, float* loss, float* stats,
+                         double* partial, unsigned int* ticket) {
+    if (!states || !d_all || !deltas || !hsteploss || !loss || !stats || !partial || !ticket || b <= 0 || t < 2 || n <= 0)
+        return fail(-1, "sur_tbptt_delta_loss: bad argument (need B > 0, T >= 2, N > 0)");
+    if (!(delta != 0.0f) || !(stdv > 0.0f)) return fail(-1, "sur_tbptt_delta_loss: delta must be non-zero and std positive");
+    return launch_checked([&] {
+        hipLaunchKernelGGL(delta_loss_kernel, dim3(t), dim3(TPB), 0, (hipStream_t)stream, states, d_all, b, t, n, delta, mean,
+                           stdv, deltas, dd_all, hsteploss, loss, stats, partial, ticket);
+    }, "delta_loss");
 }
 
 }  // extern "C"

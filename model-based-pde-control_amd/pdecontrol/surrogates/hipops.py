@@ -43,10 +43,13 @@ SYMBOLS = (
     ("sur_encoder_forward", [_fp, _EP, _fp, _i, _fp]),
     ("sur_encoder_backward", [_fp, _EP, _fp, _fp, _i, _fp, _i, _i]),
     ("sur_flush_encoder_grads", [_fp, _EP]),
-    ("sur_chunk_forward", [_fp, _CP, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _fp, _fp, _fp, _fp]),
+    ("sur_chunk_saved_floats", [_CP]),
+    ("sur_chunk_forward", [_fp, _CP, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _fp, _fp, _fp, _fp, _fp]),
     ("sur_chunk_backward", [_fp, _CP, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _fp, _fp, _fp, _fp,
-                            _i]),
+                            _i, _fp]),
     ("sur_flush_chunk_grads", [_fp, _CP]),
+    ("sur_tbptt_delta_loss", [_fp, _fp, _fp, _i, _i, _i, ctypes.c_float, ctypes.c_float, ctypes.c_float, _fp, _fp, _fp, _fp,
+                              _fp, _fp, _fp]),
 )
 _lib = None
 
@@ -167,6 +170,20 @@ def _dscale_constants(dscaling):
     raise SurrogateHipError("fused rollout supports dscaling = identity or Normalize(scalar stats).Inverse only")
 
 
+def undscale_constants(undscaling):
+    """(mean, std) such that undscaling(x) == (x - mean) / std for the two forms the controller builds
+    (mbrl.py:168-171): identity, or a Normalize with scalar statistics.  None for anything else."""
+    from pdegym.common import transforms as T
+    inner = getattr(undscaling, "transform", None)
+    if isinstance(undscaling, T.BatchTransform) and isinstance(inner, T.Identity):
+        return 0.0, 1.0
+    if isinstance(undscaling, T.BatchTransform) and isinstance(inner, T.Normalize) and inner.mean is not None \
+            and inner.mean.numel() == 1:
+        var = inner.var.reshape(-1)[0].to(torch.float32).cpu()
+        return float(inner.mean.reshape(-1)[0]), float(torch.sqrt(var + inner.epsilon))
+    return None
+
+
 def _chunk_pack(surrogate, rows):
     from pdecontrol.surrogates.models.cnn import ConvBlock, DeConvolutionBlock
     from pdecontrol.surrogates.transition import CNNLSTMTransitionModel
@@ -211,6 +228,7 @@ class FusedPacks:
         self.key = self._key(surrogate, n)
         self._flush_queued = False
         self.side_streams = []
+        self.loss_scratch = {}
 
     @staticmethod
     def _key(surrogate, n):
@@ -234,8 +252,20 @@ class FusedPacks:
     def flush(self):
         """Reduce every pending partial-gradient row into param.grad (3 tiny launches at most)."""
         self._flush_queued = False
-        for pack in self.packs:
-            pack.flush()
+        dirty = [pack for pack in self.packs if pack.dirty]
+        if not dirty:
+            return
+        # the reductions are independent: the first stays on the current stream, the others run beside it
+        dev = dirty[0].params[0].device
+        forks = []
+        for pack, stream in zip(dirty[1:], _side_streams(self, dev, len(dirty) - 1)):
+            fork = _Fork(stream)
+            with fork:
+                pack.flush()
+            forks.append(fork)
+        dirty[0].flush()
+        for fork in forks:
+            fork.join()
 
     def schedule_flush(self):
         """Called from inside a backward: run ``flush`` when the current backward pass finishes."""
@@ -281,6 +311,16 @@ class _EncoderFn(torch.autograd.Function):
         return dx, None, None, None
 
 
+SAVE_ACTIVATIONS = True   # False: the backward kernel recomputes each step's forward (bit-identical, slower)
+
+
+def _saved_buffer(pack, k, b, device):
+    """[K, B, F] buffer for the forward intermediates the backward kernel streams back instead of recomputing
+    (None if the library has no saved-activation path for this geometry)."""
+    f = load().sur_chunk_saved_floats(ctypes.byref(pack.c)) if SAVE_ACTIVATIONS else 0
+    return torch.empty((k, b, f), device=device, dtype=torch.float32) if f > 0 else None
+
+
 class _ChunkFn(torch.autograd.Function):
     """K rollout steps in one launch; inputs / outputs are time-major (see surrogate_hip.h)."""
 
@@ -295,9 +335,11 @@ class _ChunkFn(torch.autograd.Function):
         c_all = torch.empty_like(h_all)
         d_all = torch.empty((k, b, 1, n), device=xlat_t.device, dtype=torch.float32)
         out_all = torch.empty_like(d_all)
+        saved = _saved_buffer(pack, k, b, xlat_t.device) if any(ctx.needs_input_grad) else None
         _check(load().sur_chunk_forward(_stream(), ctypes.byref(pack.c), _p(xlat_t), _p(lstates_t), _p(states_t), _p(h0),
-                                        _p(c0), k, s, b, _p(h_all), _p(c_all), _p(d_all), _p(out_all)))
+                                        _p(c0), k, s, b, _p(h_all), _p(c_all), _p(d_all), _p(out_all), _p(saved)))
         ctx.save_for_backward(xlat_t, lstates_t, h0, c0, h_all, c_all)
+        ctx.fwd_saved = saved
         ctx.pack, ctx.owner = pack, owner
         ctx.needs = (xlat_t.requires_grad, lstates_t.requires_grad, h0.requires_grad, c0.requires_grad)
         ctx.set_materialize_grads(False)
@@ -316,10 +358,50 @@ class _ChunkFn(torch.autograd.Function):
         k, b = xlat_t.shape[:2]
         _check(load().sur_chunk_backward(_stream(), ctypes.byref(ctx.pack.c), _p(xlat_t), _p(lstates_t), _p(h0), _p(c0),
                                          _p(h_all), _p(c_all), _p(dd_all), _p(dout_all), _p(dh_all), _p(dc_all), k,
-                                         lstates_t.shape[0], b, _p(dxlat), _p(dlst), _p(dh0), _p(dc0), 0))
+                                         lstates_t.shape[0], b, _p(dxlat), _p(dlst), _p(dh0), _p(dc0), 0,
+                                         _p(ctx.fwd_saved)))
+        ctx.fwd_saved = None
         ctx.pack.dirty = True
         ctx.owner.schedule_flush()
         return dxlat, dlst, None, dh0, dc0, None, None, None
+
+
+class _DeltaLossFn(torch.autograd.Function):
+    """Delta-mode TBPTT loss, its time-resolved mean, the logged statistics and d loss / d d_all in one launch
+    (sur_tbptt_delta_loss, include/surrogate_hip.h)."""
+
+    @staticmethod
+    def forward(ctx, d_all, states, delta, mean, stdv, scratch):
+        t, b, _, n = d_all.shape
+        dev = d_all.device
+        d_all, states = d_all.contiguous(), states.contiguous()
+        new = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)
+        deltas, hstep, loss, stats = new(b, t - 1, 1, n), new(t - 1), new(), new(4)
+        dd = torch.empty_like(d_all) if ctx.needs_input_grad[0] else None
+        partial, ticket = scratch
+        _check(load().sur_tbptt_delta_loss(_stream(), _p(states), _p(d_all), b, t, n, delta, mean, stdv, _p(deltas), _p(dd),
+                                           _p(hstep), _p(loss), _p(stats), _p(partial), _p(ticket)))
+        ctx.dd = dd
+        ctx.mark_non_differentiable(deltas, hstep, stats)
+        return loss, hstep, stats, deltas
+
+    @staticmethod
+    def backward(ctx, g_loss, *_):
+        dd, ctx.dd = ctx.dd, None
+        return (None if dd is None or g_loss is None else dd * g_loss), None, None, None, None, None
+
+
+def fused_delta_loss(surrogate, d_all, states, delta, mean, stdv):
+    """d_all: time-major predicted deltas [T,B,1,N] (autograd output of the fused TBPTT forward); states [B,T,1,N].
+    Returns (loss, hsteploss [T-1], stats [4] = mean/std of predicted then true deltas, true deltas [B,T-1,1,N])."""
+    owner = surrogate._fused_packs
+    t = d_all.shape[0]
+    scratch = owner.loss_scratch.get(t)
+    if scratch is None:
+        scratch = (torch.empty(5 * t, device=d_all.device, dtype=torch.float64),
+                   torch.zeros(1, device=d_all.device, dtype=torch.int32))
+        owner.loss_scratch[t] = scratch
+    return _DeltaLossFn.apply(d_all, states, float(delta), float(mean), float(stdv), scratch)
 
 
 def encode(x, pack, owner):
@@ -448,7 +530,7 @@ class _TBPTTFn(torch.autograd.Function):
         tm = surrogate.transition_model
         h0 = tm.H0.unsqueeze(0).expand(b, -1, -1).contiguous()
         c0 = tm.C0.unsqueeze(0).expand(b, -1, -1).contiguous()
-        seeds, h0s, c0s, h_alls, c_alls = [states_t0], [h0], [c0], [], []
+        seeds, h0s, c0s, h_alls, c_alls, saveds = [states_t0], [h0], [c0], [], [], []
         d_all = torch.empty((t_total, b, 1, n), device=dev, dtype=torch.float32)
         out_all = torch.empty_like(d_all)
         for c, (k0, k1) in enumerate(bounds):
@@ -463,13 +545,15 @@ class _TBPTTFn(torch.autograd.Function):
             h_all = torch.empty((k, b, cs, hq), device=dev, dtype=torch.float32)
             c_all = torch.empty_like(h_all)
             s_used = min(seeds[c].shape[0], k)
+            saved = _saved_buffer(owner.chunk, k, b, dev)
             _check(lib.sur_chunk_forward(_stream(), ctypes.byref(owner.chunk.c), _p(lactions_t[k0:k1]), _p(lstates[c]),
                                          _p(seeds[c]), _p(h0s[c]), _p(c0s[c]), k, s_used, b, _p(h_all), _p(c_all),
-                                         _p(d_all[k0:k1]), _p(out_all[k0:k1])))
+                                         _p(d_all[k0:k1]), _p(out_all[k0:k1]), _p(saved)))
             h_alls.append(h_all)
             c_alls.append(c_all)
+            saveds.append(saved)
         ctx.owner, ctx.bounds, ctx.dims = owner, bounds, (b, t_total, n, nchunks)
-        ctx.saved = (actions_t, lactions_t, seeds, lstates, h0s, c0s, h_alls, c_alls)
+        ctx.saved = (actions_t, lactions_t, seeds, lstates, h0s, c0s, h_alls, c_alls, saveds)
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(out_all)
         return d_all, out_all, h_alls[-1][-1], c_alls[-1][-1]
@@ -478,7 +562,7 @@ class _TBPTTFn(torch.autograd.Function):
     def backward(ctx, dd_all, _dout, _dh, _dc):
         owner, bounds = ctx.owner, ctx.bounds
         b, t_total, n, nchunks = ctx.dims
-        actions_t, lactions_t, seeds, lstates, h0s, c0s, h_alls, c_alls = ctx.saved
+        actions_t, lactions_t, seeds, lstates, h0s, c0s, h_alls, c_alls, saveds = ctx.saved
         lib = load()
         dev = actions_t.device
         if dd_all is None:
@@ -490,6 +574,7 @@ class _TBPTTFn(torch.autograd.Function):
         owner.state_enc.ensure_rows(sum(enc_rows))
         owner.refresh_partials()
         streams = _side_streams(owner, dev, nchunks)
+        main = torch.cuda.current_stream(dev)
         forks, row0 = [], 0
         for c, (k0, k1) in enumerate(bounds):
             fork = _Fork(streams[c])
@@ -498,17 +583,23 @@ class _TBPTTFn(torch.autograd.Function):
                 _check(lib.sur_chunk_backward(_stream(), ctypes.byref(owner.chunk.c), _p(lactions_t[k0:k1]), _p(lstates[c]),
                                               _p(h0s[c]), _p(c0s[c]), _p(h_alls[c]), _p(c_alls[c]), _p(dd_all[k0:k1]), None,
                                               None, None, k1 - k0, min(seeds[c].shape[0], k1 - k0), b,
-                                              _p(dxlat_all[k0:k1]), _p(dlst), None, None, c * b))
+                                              _p(dxlat_all[k0:k1]), _p(dlst), None, None, c * b, _p(saveds[c])))
+                if fork.stream is not main:
+                    # the action-encoder backward below only needs this chunk's dxlat: it must not wait for the
+                    # state-encoder backward that follows on this side stream
+                    done = torch.cuda.Event()
+                    done.record(fork.stream)
+                    main.wait_event(done)
                 m = lstates[c].shape[0] * b
                 _check(lib.sur_encoder_backward(_stream(), ctypes.byref(owner.state_enc.c), _p(seeds[c]), _p(dlst), m, None,
                                                 row0, enc_rows[c]))
                 dlst.record_stream(fork.stream)
             row0 += enc_rows[c]
             forks.append(fork)
-        for fork in forks:
-            fork.join()
         _check(lib.sur_encoder_backward(_stream(), ctypes.byref(owner.action_enc.c), _p(actions_t), _p(dxlat_all),
                                         t_total * b, None, 0, min(ENCODER_ROWS, owner.action_enc.c.rows)))
+        for fork in forks:
+            fork.join()
         for pack in owner.packs:
             pack.dirty = True
         owner.schedule_flush()
@@ -517,8 +608,9 @@ class _TBPTTFn(torch.autograd.Function):
 
 def fused_tbptt(surrogate, states, actions, tau, tbtt):
     """TBPTT forward of PDETrainingModule (training.py:71-98) on the fused kernels.  Returns
-    (outputs [B,T,1,N], outdeltas [B,T,1,N], (H, C)) with one action per step (the training layout)."""
+    (outputs [B,T,1,N], outdeltas [B,T,1,N], (H, C), time-major outdeltas [T,B,1,N]) with one action per step
+    (the training layout)."""
     b, _, _, n = states.shape
     owner = packs_for(surrogate, n, b)
     d_all, out_all, h, c = _TBPTTFn.apply(states, actions, owner.anchor, owner, surrogate, tau, tbtt)
-    return out_all.transpose(0, 1), d_all.transpose(0, 1), (h, c)
+    return out_all.transpose(0, 1), d_all.transpose(0, 1), (h, c), d_all

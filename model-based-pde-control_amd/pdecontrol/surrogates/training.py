@@ -57,8 +57,10 @@ class PDETrainingModule(pl.LightningModule):
         if ops.use_fused(states) and isinstance(self.surrogate, AutoRegPDESurrogate):
             # every chunk in a handful of launches, independent work on parallel streams (hipops._TBPTTFn)
             from pdecontrol.surrogates import hipops
-            outputs, deltas, hidden = hipops.fused_tbptt(self.surrogate, states, actions, self.tau, self.tbtt)
-            return [ModelRollout(outputs=outputs, deltas=deltas, hidden=tuple(h.detach() for h in hidden))]
+            outputs, deltas, hidden, d_all = hipops.fused_tbptt(self.surrogate, states, actions, self.tau, self.tbtt)
+            out = ModelRollout(outputs=outputs, deltas=deltas, hidden=tuple(h.detach() for h in hidden))
+            out.time_major_deltas = d_all
+            return [out]
         rollouts = []
         seed_states, hidden = None, None
         if isinstance(self.surrogate, AutoRegPDESurrogate):
@@ -76,26 +78,49 @@ class PDETrainingModule(pl.LightningModule):
             self.surrogate.reencode_predictions = True
         return rollouts
 
+    def _fused_delta_loss(self, rollouts, states):
+        """The loss section of training_step as one HIP launch, when the step ran on the fused kernels and the
+        configuration is the controller's (delta mode, MSELoss(reduction="none"), affine undscaling)."""
+        d_all = getattr(rollouts[0], "time_major_deltas", None) if len(rollouts) == 1 else None
+        if d_all is None or self.training_mode != "delta":
+            return None
+        if not (isinstance(self.loss, torch.nn.MSELoss) and self.loss.reduction == "none"):
+            return None
+        from pdecontrol.surrogates import hipops
+        consts = hipops.undscale_constants(self.undscaling)
+        if consts is None or states.dtype != torch.float32 or states.shape[2] != 1:
+            return None
+        return hipops.fused_delta_loss(self.surrogate, d_all, states, self.delta, *consts)
+
     def training_step(self, batch, bidx):
         states, actions, *_ = batch
         rollouts = self.tbptt_forward(states, actions)
 
-        outputs = torch.cat([r.outputs for r in rollouts], dim=1)
-        outdeltas = torch.cat([r.deltas for r in rollouts], dim=1)[:, :-1]
-        deltas = self.undscaling(torch.diff(states, dim=1) / self.delta)
-        if self.training_mode == "delta":
-            loss = self.loss(outdeltas, deltas)
+        fused = self._fused_delta_loss(rollouts, states)
+        if fused is not None:
+            # loss, per-step loss, the four logged statistics and d loss / d deltas: one launch
+            loss, hsteploss, stats, deltas = fused
+            outputs, outdeltas = rollouts[0].outputs, rollouts[0].deltas[:, :-1]
+            m_out, s_out, m_true, s_true = stats[0], stats[1], stats[2], stats[3]
         else:
-            decoded = torch.cat((states[:, :1], outputs[:, :-1]), dim=1)
-            loss = self.loss(decoded, states)
-        hsteploss = loss.mean(dim=(0, 2, 3))
-        loss = loss.mean()
+            outputs = torch.cat([r.outputs for r in rollouts], dim=1)
+            outdeltas = torch.cat([r.deltas for r in rollouts], dim=1)[:, :-1]
+            deltas = self.undscaling(torch.diff(states, dim=1) / self.delta)
+            if self.training_mode == "delta":
+                loss = self.loss(outdeltas, deltas)
+            else:
+                decoded = torch.cat((states[:, :1], outputs[:, :-1]), dim=1)
+                loss = self.loss(decoded, states)
+            hsteploss = loss.mean(dim=(0, 2, 3))
+            loss = loss.mean()
+            m_out, s_out = outdeltas.detach().mean(), outdeltas.detach().std()
+            m_true, s_true = deltas.detach().mean(), deltas.detach().std()
 
         self.log("Train Loss", loss.detach(), on_step=False, on_epoch=True)
-        self.log("Train Mean Delta Output", outdeltas.detach().mean(), on_step=False, on_epoch=True)
-        self.log("Train Std. Delta Output", outdeltas.detach().std(), on_step=False, on_epoch=True)
-        self.log("Train Mean Delta", deltas.detach().mean(), on_step=False, on_epoch=True)
-        self.log("Train Std. Delta", deltas.detach().std(), on_step=False, on_epoch=True)
+        self.log("Train Mean Delta Output", m_out, on_step=False, on_epoch=True)
+        self.log("Train Std. Delta Output", s_out, on_step=False, on_epoch=True)
+        self.log("Train Mean Delta", m_true, on_step=False, on_epoch=True)
+        self.log("Train Std. Delta", s_true, on_step=False, on_epoch=True)
 
         return {"loss": loss, "hsteploss": hsteploss.detach(), "outputs": outputs.detach(),
                 "actions": actions.detach(), "states": states.detach(), "outdeltas": outdeltas.detach(),

@@ -205,3 +205,65 @@ def test_ensemble_parallel_step_equals_member_by_member(dev):
         assert len({l[0] for l in ens_losses}) == 3  # members really are different models / batches
     finally:
         ops.enable_fused(False)
+
+
+@pytest.mark.parametrize("N", [64, 256])
+def test_saved_activations_backward_is_bit_identical_to_recompute(dev, N, monkeypatch):
+    """sur_chunk_backward fed with the forward's saved intermediates == recomputing them in the kernel."""
+    from pdecontrol.surrogates import hipops, ops
+    g = torch.Generator().manual_seed(3)
+    states = (torch.rand(8, 20, 1, N, generator=g) * 2 - 1).to(dev)
+    actions = (torch.rand(8, 20, 1, N, generator=g) * 2 - 1).to(dev)
+    grads, losses = [], []
+    try:
+        ops.enable_fused(True)
+        for save in (True, False):
+            monkeypatch.setattr(hipops, "SAVE_ACTIVATIONS", save)
+            m = _build(dev, N=N)
+            out = m.training_step((states, actions), 0)
+            out["loss"].backward()
+            torch.cuda.synchronize()
+            grads.append(_grads(m))
+            losses.append(float(out["loss"].detach()))
+            if save:
+                f = hipops.load().sur_chunk_saved_floats(__import__("ctypes").byref(m.surrogate._fused_packs.chunk.c))
+                assert f > 0, "saved-activation path not available for this geometry"
+    finally:
+        ops.enable_fused(False)
+    assert losses[0] == losses[1]
+    assert grads[0].keys() == grads[1].keys() and len(grads[0]) > 20
+    for k in grads[0]:
+        assert torch.equal(grads[0][k], grads[1][k]), k
+
+
+@pytest.mark.parametrize("scaled", [True, False])
+def test_fused_delta_loss_matches_torch_ops(dev, scaled):
+    """sur_tbptt_delta_loss (loss, per-step loss, logged statistics, true deltas, gradient) against the torch-op
+    spelling of training.py:100-121 on the same fused rollout."""
+    from pdecontrol.surrogates import hipops, ops
+    g = torch.Generator().manual_seed(11)
+    states = (torch.rand(16, 20, 1, 64, generator=g) * 2 - 1).to(dev)
+    actions = (torch.rand(16, 20, 1, 64, generator=g) * 2 - 1).to(dev)
+    res = {}
+    try:
+        ops.enable_fused(True)
+        for mode in ("fused_loss", "torch_loss"):
+            m = _build(dev, scaled=scaled)
+            if mode == "torch_loss":
+                m._fused_delta_loss = lambda rollouts, states: None
+            out = m.training_step((states, actions), 0)
+            out["loss"].backward()
+            torch.cuda.synchronize()
+            res[mode] = (out, dict(m.logged), _grads(m))
+    finally:
+        ops.enable_fused(False)
+    (of, lf, gf), (ot, lt, gt) = res["fused_loss"], res["torch_loss"]
+    assert of["loss"].shape == ot["loss"].shape == ()
+    np.testing.assert_allclose(float(of["loss"].detach()), float(ot["loss"].detach()), rtol=2e-6)
+    np.testing.assert_allclose(of["hsteploss"].cpu().numpy(), ot["hsteploss"].cpu().numpy(), rtol=2e-6)
+    assert torch.equal(of["deltas"], ot["deltas"])          # same fp32 expression, element by element
+    assert torch.equal(of["outdeltas"], ot["outdeltas"]) and torch.equal(of["outputs"], ot["outputs"])
+    for name in ("Train Loss", "Train Mean Delta Output", "Train Std. Delta Output", "Train Mean Delta", "Train Std. Delta"):
+        np.testing.assert_allclose(float(lf[name]), float(lt[name]), rtol=1e-5, atol=1e-7, err_msg=name)
+    for k in gt:
+        _close(gf[k], gt[k], rtol=1e-5, atol_scale=1e-6, msg=k)
