@@ -108,7 +108,7 @@ int sur_flush_chunk_grads(void* stream, const sur_chunk_params* p);
  *                  d_all[:T-1], then of the true deltas (the four "Train ... Delta" metrics)
  *   dd_all       = d loss / d d_all  [T,B,1,N] (last step zero), may be NULL
  * states [B,T,1,N]; d_all [T,B,1,N] time-major as written by sur_chunk_forward; deltas [B,T-1,1,N];
- * hsteploss [T-1]; loss [1]; stats [4]; partial: scratch of 5*T doubles; ticket: one zero-initialised
+ * hsteploss [T-1]; loss [1]; stats [4]; partial: scratch of 40*T doubles; ticket: one zero-initialised
  * unsigned the kernel leaves at zero.  Sums are fp64 and reduced in a fixed order (deterministic). */
 int sur_tbptt_delta_loss(void* stream, const float* states, const float* d_all, int b, int t, int n, float delta, float mean,
                          float stdv, float* deltas, float* dd_all, float* hsteploss, float* loss, float* stats,

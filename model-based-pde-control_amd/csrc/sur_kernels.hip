@@ -27,7 +27,7 @@
 // Diagnostic build only (-DSUR_STAMP): shader-clock stamps per phase of chunk_fwd for workgroup 0,
 // accumulated in a __device__ buffer nothing else reads (guide section 7, In-kernel stamps).
 #ifdef SUR_STAMP
-__device__ long long sur_stamp_buf[32];
+__device__ long long sur_stamp_buf[64];
 __device__ long long sur_stamp_last;
 #define STAMP(id)                                                                 \
     do {                                                                          \
@@ -516,10 +516,27 @@ __device__ void stage_weights(const float* const* gw, const int* size, float* ld
     int off = 0;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-        float* dst = lds_w + off;
-        for (int j = threadIdx.x; j < size[i]; j += blockDim.x) dst[j] = gw[i][j];
-        v.w[i] = dst;
+        v.w[i] = lds_w + off;
         off += size[i];
+    }
+    // first TPB elements of every parameter (all of it for the small ones): NP independent loads in flight at once
+    float head[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) head[i] = (int)threadIdx.x < size[i] ? gw[i][threadIdx.x] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < NP; ++i)
+        if ((int)threadIdx.x < size[i]) const_cast<float*>(v.w[i])[threadIdx.x] = head[i];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        float* dst = const_cast<float*>(v.w[i]);
+        for (int j = threadIdx.x + TPB; j < size[i]; j += 4 * TPB) {   // the tails of the large ones, four loads per round
+            float t[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) t[u] = j + u * TPB < size[i] ? gw[i][j + u * TPB] : 0.0f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (j + u * TPB < size[i]) dst[j + u * TPB] = t[u];
+        }
     }
     __syncthreads();
 }
@@ -535,6 +552,25 @@ __device__ void setup_grads(const int* size, float* base, bool zero, ParamViews<
     if (zero)
         for (int j = threadIdx.x; j < off; j += blockDim.x) base[j] = 0.0f;
     __syncthreads();
+}
+
+// row[j] += acc[j] for the workgroup's partial-gradient row.  The global loads of a batch are all issued before
+// the first add/store: as a plain loop this read-modify-write paid one HBM round trip per iteration (20-30 of them).
+__device__ __forceinline__ void add_to_row(float* __restrict__ row, const float* acc, int psize) {
+    constexpr int U = 8;
+    for (int j0 = threadIdx.x; j0 < psize; j0 += U * TPB) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = j0 + u * TPB;
+            v[u] = j < psize ? row[j] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = j0 + u * TPB;
+            if (j < psize) row[j] = v[u] + acc[j];
+        }
+    }
 }
 
 template <int NP>
@@ -660,37 +696,51 @@ __global__ void __launch_bounds__(TPB) enc_fwd_kernel(const sur_encoder_params p
     }
 }
 
-__global__ void __launch_bounds__(TPB) enc_bwd_kernel(const sur_encoder_params p, const float* __restrict__ x,
+// Two workgroups per CU (2 waves per SIMD): the kernel is bound by dependent-phase latency, so a second resident
+// workgroup fills the issue slots the first one leaves empty.  Costs ~118 spilled dwords, measured +10 % on the step.
+#ifndef ENC_BWD_OCC
+#define ENC_BWD_OCC 2
+#endif
+__global__ void __launch_bounds__(TPB, ENC_BWD_OCC) enc_bwd_kernel(const sur_encoder_params p, const float* __restrict__ x,
                                                       const float* __restrict__ dz, int m_total, float* __restrict__ dx,
                                                       int grads_in_lds, int row_base) {
     extern __shared__ __align__(16) float lds[];
+    STAMP(32);
     EncLayout L;
     enc_layout(p, lds, true, L);
     ParamViews<SUR_ENC_NPARAM> v;
     stage_weights<SUR_ENC_NPARAM>(p.w, p.size, L.end, v);
+    STAMP(33);
     const int psize = psize_of<SUR_ENC_NPARAM>(p.size);
     float* row = p.partial + (size_t)(row_base + blockIdx.x) * psize;
     float* gacc = grads_in_lds ? L.end + psize : row;
     setup_grads<SUR_ENC_NPARAM>(p.size, gacc, grads_in_lds != 0, v);
+    STAMP(34);
     const int nin = p.c[0] * p.n, nout = L.rb[2].cout * L.rb[2].hout;
     for (int m = blockIdx.x; m < m_total; m += gridDim.x) {
         lds_load(L.rb[0].in, x + (size_t)m * nin, nin);
+        STAMP(35);
 #pragma unroll
         for (int b = 0; b < 3; ++b) rb_forward(L.rb[b], v.w + b * SUR_RB_NPARAM);
+        STAMP(36);
         lds_load(L.dA, dz + (size_t)m * nout, nout);
+        STAMP(37);
         float *dout = L.dA, *din = L.dB;
 #pragma unroll
         for (int b = 2; b >= 0; --b) {
             rb_backward(L.rb[b], v.w + b * SUR_RB_NPARAM, v.g + b * SUR_RB_NPARAM, dout, din, L.g1, L.g2, L.g3, L.xh);
+            STAMP(38 + b);
             float* t = dout;
             dout = din;
             din = t;
         }
         if (dx) lds_store(dx + (size_t)m * nin, dout, nin);
+        STAMP(41);
     }
     if (grads_in_lds) {
-        for (int j = threadIdx.x; j < psize; j += blockDim.x) row[j] += gacc[j];
+        add_to_row(row, gacc, psize);
     }
+    STAMP(42);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -698,11 +748,13 @@ __global__ void __launch_bounds__(TPB) enc_bwd_kernel(const sur_encoder_params p
 // (pdecontrol/surrogates/training.py:100-121): true deltas from the state sequence, the undscaling
 // forward, the element-wise MSE, its time-resolved and overall means, the four logged statistics and
 // the gradient of the mean loss wrt the predicted deltas.
-//   grid = T workgroups: workgroup t < T-1 handles time step t of all samples, workgroup T-1 only zeroes
-//   the (unused) last step's gradient.  Partial sums are fp64 and reduced in a fixed order by the
+//   grid = T x nsplit workgroups: row t < T-1 handles time step t of all samples, row T-1 only zeroes the
+//   (unused) last step's gradient.  Partial sums are fp64 and reduced in a fixed order by the
 //   workgroup that arrives last (ticket counter), so the result does not depend on scheduling.
 // ---------------------------------------------------------------------------------------------
 constexpr int LOSS_NSUM = 5;  // squared error, sum / sum of squares of predicted deltas, same of true deltas
+constexpr int LOSS_UNROLL = 4;
+constexpr int LOSS_MAX_SPLIT = 8;
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -717,27 +769,43 @@ delta_loss_kernel(const float* __restrict__ states, const float* __restrict__ d_
                   double* __restrict__ partial, unsigned int* __restrict__ ticket) {
     __shared__ double red[TPB / 64][LOSS_NSUM];
     __shared__ bool last;
-    const int t = blockIdx.x, per_t = B * N;
+    // blockIdx.x = time step, blockIdx.y = slice of the B*N elements of that step; LOSS_UNROLL elements per
+    // thread per round with every load of the round issued before the first use
+    const int t = blockIdx.x, per_t = B * N, nsplit = gridDim.y;
     const double count = (double)per_t * (T - 1);
     double acc[LOSS_NSUM] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    const int stride = nsplit * TPB;
     if (t < T - 1) {
         const float gscale = (float)(2.0 / count);
-        for (int e = threadIdx.x; e < per_t; e += blockDim.x) {
-            const int b = e / N, i = e - b * N;
-            const size_t sidx = ((size_t)b * T + t) * N + i;
-            const float dl = ((states[sidx + N] - states[sidx]) / delta - mean) / stdv;
-            const float od = d_all[((size_t)t * B + b) * N + i];
-            deltas[((size_t)b * (T - 1) + t) * N + i] = dl;
-            const float err = od - dl;
-            if (dd_all) dd_all[((size_t)t * B + b) * N + i] = gscale * err;
-            acc[0] += (double)(err * err);
-            acc[1] += od;
-            acc[2] += (double)od * od;
-            acc[3] += dl;
-            acc[4] += (double)dl * dl;
+        for (int e0 = blockIdx.y * TPB + threadIdx.x; e0 < per_t; e0 += LOSS_UNROLL * stride) {
+            float s0[LOSS_UNROLL], s1[LOSS_UNROLL], od[LOSS_UNROLL];
+#pragma unroll
+            for (int u = 0; u < LOSS_UNROLL; ++u) {
+                const int e = e0 + u * stride, ec = e < per_t ? e : e0;
+                const int b = ec / N, i = ec - b * N;
+                const size_t sidx = ((size_t)b * T + t) * N + i;
+                s0[u] = states[sidx];
+                s1[u] = states[sidx + N];
+                od[u] = d_all[((size_t)t * B + b) * N + i];
+            }
+#pragma unroll
+            for (int u = 0; u < LOSS_UNROLL; ++u) {
+                const int e = e0 + u * stride;
+                if (e >= per_t) continue;
+                const int b = e / N, i = e - b * N;
+                const float dl = ((s1[u] - s0[u]) / delta - mean) / stdv;
+                deltas[((size_t)b * (T - 1) + t) * N + i] = dl;
+                const float err = od[u] - dl;
+                if (dd_all) dd_all[((size_t)t * B + b) * N + i] = gscale * err;
+                acc[0] += (double)(err * err);
+                acc[1] += od[u];
+                acc[2] += (double)od[u] * od[u];
+                acc[3] += dl;
+                acc[4] += (double)dl * dl;
+            }
         }
     } else if (dd_all) {
-        for (int e = threadIdx.x; e < per_t; e += blockDim.x) dd_all[(size_t)t * per_t + e] = 0.0f;
+        for (int e = blockIdx.y * TPB + threadIdx.x; e < per_t; e += stride) dd_all[(size_t)t * per_t + e] = 0.0f;
     }
 #pragma unroll
     for (int j = 0; j < LOSS_NSUM; ++j) {
@@ -748,26 +816,35 @@ delta_loss_kernel(const float* __restrict__ states, const float* __restrict__ d_
     if (threadIdx.x < LOSS_NSUM) {
         double v = 0.0;
         for (int w = 0; w < TPB / 64; ++w) v += red[w][threadIdx.x];
-        partial[(size_t)t * LOSS_NSUM + threadIdx.x] = v;
+        partial[((size_t)t * nsplit + blockIdx.y) * LOSS_NSUM + threadIdx.x] = v;
     }
     __threadfence();
     __syncthreads();
-    if (threadIdx.x == 0) last = (atomicAdd(ticket, 1u) == (unsigned)(gridDim.x - 1));
+    if (threadIdx.x == 0) last = (atomicAdd(ticket, 1u) == (unsigned)(gridDim.x * gridDim.y - 1));
     __syncthreads();
     if (!last) return;
     __threadfence();
+    // fixed-order reduction of the (T-1) x nsplit partial sums by the workgroup that arrived last
     const volatile double* part = partial;
-    for (int tt = threadIdx.x; tt < T - 1; tt += blockDim.x) hsteploss[tt] = (float)(part[(size_t)tt * LOSS_NSUM] / per_t);
+    __shared__ double tsum[LOSS_NSUM];
+    for (int tt = threadIdx.x; tt < T - 1; tt += blockDim.x) {
+        double se = 0.0;
+        for (int y = 0; y < nsplit; ++y) se += part[((size_t)tt * nsplit + y) * LOSS_NSUM];
+        hsteploss[tt] = (float)(se / per_t);
+    }
+    if (threadIdx.x < LOSS_NSUM) {
+        double tot = 0.0;
+        for (int q = 0; q < (T - 1) * nsplit; ++q) tot += part[(size_t)q * LOSS_NSUM + threadIdx.x];
+        tsum[threadIdx.x] = tot;
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
-        double tot[LOSS_NSUM] = {0.0, 0.0, 0.0, 0.0, 0.0};
-        for (int tt = 0; tt < T - 1; ++tt)
-            for (int j = 0; j < LOSS_NSUM; ++j) tot[j] += part[(size_t)tt * LOSS_NSUM + j];
-        *loss = (float)(tot[0] / count);
-        const double m_od = tot[1] / count, m_dl = tot[3] / count;
+        *loss = (float)(tsum[0] / count);
+        const double m_od = tsum[1] / count, m_dl = tsum[3] / count;
         stats[0] = (float)m_od;
-        stats[1] = (float)sqrt(fmax(tot[2] - count * m_od * m_od, 0.0) / (count - 1.0));  // unbiased, like Tensor.std()
+        stats[1] = (float)sqrt(fmax(tsum[2] - count * m_od * m_od, 0.0) / (count - 1.0));  // unbiased, like Tensor.std()
         stats[2] = (float)m_dl;
-        stats[3] = (float)sqrt(fmax(tot[4] - count * m_dl * m_dl, 0.0) / (count - 1.0));
+        stats[3] = (float)sqrt(fmax(tsum[4] - count * m_dl * m_dl, 0.0) / (count - 1.0));
         *ticket = 0u;  // ready for the next launch (graph replay)
     }
 }
@@ -777,6 +854,7 @@ delta_loss_kernel(const float* __restrict__ states, const float* __restrict__ d_
 // ---------------------------------------------------------------------------------------------
 struct StepLayout {
     float *x, *h, *c, *gates, *cnew, *hnew, *p0, *a0, *p1, *a1, *p2, *a2, *d, *outv;
+    float* blk[2];  // staged backward: the two copies of the [gates .. a2] block
     // backward only
     float *dgates, *dh, *gA, *gB, *xh, *dx, *dhin, *dh_carry, *dc_carry, *dout_carry;
     float* end;
@@ -788,29 +866,33 @@ __host__ __device__ inline int step_max_act(const sur_chunk_params& p) {
     return a > b ? a : b;
 }
 
-__host__ __device__ inline int step_act_floats(const sur_chunk_params& p, bool backward) {
-    const int s = p.cs * p.hq, n = 4 * p.hq;
-    int total = p.ca * p.hq + 2 * s + 4 * s + 2 * s + 2 * p.cs * 2 * p.hq + 2 * p.c_mid * n + 4 * n;
-    if (backward) total += 4 * s + s + 3 * step_max_act(p) + p.ca * p.hq + s + 2 * s + n;
-    return total;
-}
-
 // Floats of one step's forward intermediates as the forward kernel can save them for the backward kernel:
-// the LDS block [gates .. a2] (activated gates, c_k, h_k, decoder pre-/post-LayerNorm activations).
-__host__ __device__ inline int step_saved_floats(const sur_chunk_params& p) {
+// the LDS block [gates .. a2] (activated gates, c_k, h_k, decoder pre-/post-LayerNorm activations), padded to
+// whole 1 KiB pieces because the backward kernel fetches it by LDS-DMA (one wave instruction = 64 x 16 B).
+constexpr int DMA_PIECE = 256;  // floats per global_load_lds_dwordx4 wave instruction
+__host__ __device__ inline int step_block_floats(const sur_chunk_params& p) {
     const int s = p.cs * p.hq, n = 4 * p.hq;
     return 6 * s + 2 * p.cs * 2 * p.hq + 2 * p.c_mid * n + 2 * n;
 }
-constexpr int SAVED_MAX_V4 = 16;  // float4 registers per thread the backward kernel may prefetch into
+__host__ __device__ inline int step_saved_floats(const sur_chunk_params& p) {
+    return (step_block_floats(p) + DMA_PIECE - 1) / DMA_PIECE * DMA_PIECE;
+}
 
-__device__ void step_layout(const sur_chunk_params& p, float* lds, bool backward, StepLayout& L) {
+// staged: the backward kernel keeps TWO copies of the [gates .. a2] block (this step's, and the one the DMA is
+// filling for the next step), each padded to step_saved_floats
+__host__ __device__ inline int step_act_floats(const sur_chunk_params& p, bool backward, bool staged = false) {
     const int s = p.cs * p.hq, n = 4 * p.hq;
-    float* cur = lds;
+    int total = p.ca * p.hq + 2 * s + step_block_floats(p) + 2 * n;
+    if (backward) total += 4 * s + s + 3 * step_max_act(p) + p.ca * p.hq + s + 2 * s + n;
+    if (staged) total += 2 * step_saved_floats(p) - step_block_floats(p);
+    return total;
+}
+
+// point the forward-intermediate views at a [gates .. a2] block
+__device__ __forceinline__ void use_block(const sur_chunk_params& p, float* base, StepLayout& L) {
+    const int s = p.cs * p.hq, n = 4 * p.hq;
+    float* cur = base;
     auto take = [&](int k) { float* r = cur; cur += k; return r; };
-    L.n = n;
-    L.x = take(p.ca * p.hq);
-    L.h = take(s);
-    L.c = take(s);
     L.gates = take(4 * s);
     L.cnew = take(s);
     L.hnew = take(s);
@@ -820,6 +902,19 @@ __device__ void step_layout(const sur_chunk_params& p, float* lds, bool backward
     L.a1 = take(p.c_mid * n);
     L.p2 = take(n);
     L.a2 = take(n);
+}
+
+__device__ void step_layout(const sur_chunk_params& p, float* lds, bool backward, StepLayout& L, bool staged = false) {
+    const int s = p.cs * p.hq, n = 4 * p.hq;
+    float* cur = lds;
+    auto take = [&](int k) { float* r = cur; cur += k; return r; };
+    L.n = n;
+    L.x = take(p.ca * p.hq);
+    L.h = take(s);
+    L.c = take(s);
+    L.blk[0] = take(staged ? step_saved_floats(p) : step_block_floats(p));
+    L.blk[1] = staged ? take(step_saved_floats(p)) : nullptr;
+    use_block(p, L.blk[0], L);
     L.d = take(n);
     L.outv = take(n);
     if (backward) {
@@ -904,7 +999,8 @@ chunk_fwd_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, con
     extern __shared__ __align__(16) float lds[];
     StepLayout L;
     step_layout(p, lds, false, L);
-    const int nsave4 = step_saved_floats(p) >> 2;
+    const int nsave4 = step_block_floats(p) >> 2;
+    const size_t save_stride = step_saved_floats(p);
     ParamViews<SUR_ST_NPARAM> v;
     stage_weights<SUR_ST_NPARAM>(p.w, p.size, L.end, v);
     const int b = blockIdx.x, s = p.cs * p.hq, nx = p.ca * p.hq, n = L.n;
@@ -927,7 +1023,7 @@ chunk_fwd_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, con
         STAMP(10);
         step_forward_body(p, L, v.w);
         if (saved) {  // every intermediate the backward kernel needs: it then skips the recomputation
-            float4* dst = reinterpret_cast<float4*>(saved + kb * (size_t)(nsave4 << 2));
+            float4* dst = reinterpret_cast<float4*>(saved + kb * save_stride);
             const float4* src = reinterpret_cast<const float4*>(L.gates);
             for (int i = threadIdx.x; i < nsave4; i += blockDim.x) dst[i] = src[i];
         }
@@ -956,20 +1052,22 @@ chunk_bwd_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, con
                  float* __restrict__ dc0, int grads_in_lds, int row_base, const float* __restrict__ saved) {
     extern __shared__ __align__(16) float lds[];
     StepLayout L;
-    step_layout(p, lds, true, L);
-    // Saved forward intermediates of step k travel HBM -> registers while step k+1 is being processed and
-    // are committed to LDS at the top of step k: the load latency is off the critical path.
-    const int nsave4 = step_saved_floats(p) >> 2;
-    float4 pre[SAVED_MAX_V4];
-    auto prefetch = [&](int k) {
-        const float4* src = reinterpret_cast<const float4*>(saved + ((size_t)k * B + blockIdx.x) * (size_t)(nsave4 << 2));
-#pragma unroll
-        for (int i = 0; i < SAVED_MAX_V4; ++i) {
-            const int idx = threadIdx.x + i * TPB;
-            if (idx < nsave4) pre[i] = src[idx];
-        }
+    const bool staged = saved != nullptr;
+    step_layout(p, lds, true, L, staged);
+    // Saved forward intermediates: step k-1's block travels HBM -> LDS by LDS-DMA (no registers: this kernel sits
+    // at the VGPR cap) into the spare copy blk[1] while step k's cell GEMMs run; the barrier that ends that phase
+    // retires the DMA, so its latency is never waited for.  The top of a step moves blk[1] into the working
+    // copy blk[0] (LDS -> LDS, a few hundred cycles) so every view keeps its fixed address.
+    const int npieces = step_saved_floats(p) / DMA_PIECE;
+    auto fetch_block = [&](int kk, float* dst) {
+        const float* src = saved + ((size_t)kk * B + blockIdx.x) * (size_t)(npieces * DMA_PIECE);
+        const int lane = threadIdx.x & 63;
+        for (int j = threadIdx.x >> 6; j < npieces; j += blockDim.x >> 6)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + j * DMA_PIECE + lane * 4),
+                                             (__attribute__((address_space(3))) void*)(dst + j * DMA_PIECE + lane * 4), 16, 0, 0);
     };
-    if (saved) prefetch(K - 1);
+    if (staged) fetch_block(K - 1, L.blk[1]);
+    const int nblock4 = step_block_floats(p) >> 2;
     ParamViews<SUR_ST_NPARAM> v;
     stage_weights<SUR_ST_NPARAM>(p.w, p.size, L.end, v);
     const int psize = psize_of<SUR_ST_NPARAM>(p.size);
@@ -993,21 +1091,14 @@ chunk_bwd_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, con
             L.h[i] = (k < S) ? lstates_t[kb * s + i] : (k > 0 ? h_all[prev] : h0[(size_t)b * s + i]);
             L.c[i] = (k > 0) ? c_all[prev] : c0[(size_t)b * s + i];
         }
-        if (saved) {
-            float4* dst = reinterpret_cast<float4*>(L.gates);
-#pragma unroll
-            for (int i = 0; i < SAVED_MAX_V4; ++i) {
-                const int idx = threadIdx.x + i * TPB;
-                if (idx < nsave4) dst[idx] = pre[i];
-            }
+        if (staged) {
+            const float4* src = reinterpret_cast<const float4*>(L.blk[1]);
+            float4* dst = reinterpret_cast<float4*>(L.blk[0]);
+            for (int i = threadIdx.x; i < nblock4; i += blockDim.x) dst[i] = src[i];
         }
         __syncthreads();
         STAMP(20);
-        if (saved) {
-            if (k > 0) prefetch(k - 1);
-        } else {
-            step_forward_body(p, L, w);
-        }
+        if (!staged) step_forward_body(p, L, w);
         STAMP(21);
 
         // ---- total gradient wrt d_k: direct + through out_k = base + delta*(d*mul + add) ----
@@ -1021,15 +1112,25 @@ chunk_bwd_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, con
         STAMP(22);
         // ---- decoder backward ----
         conv_bwd_weight<5>(L.gA, 1, L.a2, 1, n, 1, 2, g[SUR_ST_CV3_W], g[SUR_ST_CV3_B], all_waves(), false);
+        STAMP(12);
         conv_bwd_data<5>(L.gA, 1, n, w[SUR_ST_CV3_W], 1, 1, 2, L.gB, false);
+        STAMP(13);
         act_ln_bwd(L.gB, L.p2, 1, n, w[SUR_ST_LN2_W], true, L.gA, L.xh, g[SUR_ST_LN2_W], g[SUR_ST_LN2_B]);
+        STAMP(14);
         conv_bwd_weight<7>(L.gA, 1, L.a1, p.c_mid, n, 1, 3, g[SUR_ST_CV2_W], g[SUR_ST_CV2_B], all_waves(), false);
+        STAMP(15);
         conv_bwd_data<7>(L.gA, 1, n, w[SUR_ST_CV2_W], p.c_mid, 1, 3, L.gB, false);
+        STAMP(16);
         act_ln_bwd(L.gB, L.p1, p.c_mid, n, w[SUR_ST_LN1_W], true, L.gA, L.xh, g[SUR_ST_LN1_W], g[SUR_ST_LN1_B]);
+        STAMP(17);
         deconv_bwd_weight(L.gA, p.c_mid, L.a0, p.cs, 2 * p.hq, g[SUR_ST_DC1_W], g[SUR_ST_DC1_B], lower_half(), false);
+        STAMP(18);
         deconv_bwd_data(L.gA, p.c_mid, 2 * p.hq, w[SUR_ST_DC1_W], p.cs, L.gB, upper_half(), true);
+        STAMP(19);
         act_ln_bwd(L.gB, L.p0, p.cs, 2 * p.hq, w[SUR_ST_LN0_W], true, L.gA, L.xh, g[SUR_ST_LN0_W], g[SUR_ST_LN0_B]);
+        STAMP(26);
         deconv_bwd_weight(L.gA, p.cs, L.hnew, p.cs, p.hq, g[SUR_ST_DC0_W], g[SUR_ST_DC0_B], lower_half(), false);
+        STAMP(27);
         deconv_bwd_data(L.gA, p.cs, p.hq, w[SUR_ST_DC0_W], p.cs, L.dh, upper_half(), true);
 
         STAMP(23);
@@ -1047,6 +1148,7 @@ chunk_bwd_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, con
         }
         __syncthreads();
         STAMP(24);
+        if (staged && k > 0) fetch_block(k - 1, L.blk[1]);
         {
             // four independent GEMMs on the gate gradients dG [4*cs][hq], issued without barriers in between:
             //   dx  [ca][hq]  = sum_g Wx_g^T * dG_g     (waves: first quarter)
@@ -1138,7 +1240,7 @@ chunk_bwd_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, con
     }
     if (grads_in_lds) {
         __syncthreads();
-        for (int j = threadIdx.x; j < psize; j += blockDim.x) row[j] += gacc[j];
+        add_to_row(row, gacc, psize);
     }
 }
 
@@ -1196,10 +1298,10 @@ extern "C" {
 const char* sur_last_error(void) { return g_err; }
 
 #ifdef SUR_STAMP
-int sur_debug_stamps(long long* out32, int reset) {
-    if (out32 && hipMemcpyFromSymbol(out32, HIP_SYMBOL(sur_stamp_buf), sizeof(long long) * 32) != hipSuccess) return -2;
+int sur_debug_stamps(long long* out64, int reset) {
+    if (out64 && hipMemcpyFromSymbol(out64, HIP_SYMBOL(sur_stamp_buf), sizeof(long long) * 64) != hipSuccess) return -2;
     if (reset) {
-        long long z[32] = {0};
+        long long z[64] = {0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(sur_stamp_buf), z, sizeof(z)) != hipSuccess) return -2;
     }
     return 0;
@@ -1248,10 +1350,10 @@ int sur_flush_encoder_grads(void* stream, const sur_encoder_params* p) {
 
 int sur_chunk_saved_floats(const sur_chunk_params* p) {
     if (!p) return 0;
-    const int total = step_saved_floats(*p);
-    // float4 granularity of the block and of its LDS position; must fit the backward kernel's prefetch registers
-    if ((p->hq & 3) || ((p->ca * p->hq) & 3) || (total >> 2) > SAVED_MAX_V4 * TPB) return 0;
-    return total;
+    // float4 granularity of the block and of its LDS position; the backward kernel's second copy must fit in LDS
+    if ((p->hq & 3) || ((p->ca * p->hq) & 3)) return 0;
+    const size_t lds = sizeof(float) * (step_act_floats(*p, true, true) + psize_of<SUR_ST_NPARAM>(p->size));
+    return lds <= LDS_LIMIT ? step_saved_floats(*p) : 0;
 }
 
 int sur_chunk_forward(void* stream, const sur_chunk_params* p, const float* xlat_t, const float* lstates_t,
@@ -1283,7 +1385,7 @@ int sur_chunk_backward(void* stream, const sur_chunk_params* p, const float* xla
     if (!p->partial || row_base < 0 || p->rows < row_base + b)
         return fail(-1, "sur_chunk_backward: partial gradient buffer has %d rows, need [%d, %d)", p->rows, row_base, row_base + b);
     const int psize = psize_of<SUR_ST_NPARAM>(p->size);
-    const size_t base = sizeof(float) * (step_act_floats(*p, true) + psize);
+    const size_t base = sizeof(float) * (step_act_floats(*p, true, saved != nullptr) + psize);
     int grads_in_lds = (base + sizeof(float) * psize <= LDS_LIMIT) ? 1 : 0;
     const size_t lds = base + (grads_in_lds ? sizeof(float) * psize : 0);
     if (int rc = set_lds(chunk_bwd_kernel, lds, "chunk backward")) return rc;
@@ -1311,8 +1413,10 @@ int sur_tbptt_delta_loss(void* stream, const float* states, const float* d_all, 
     if (!states || !d_all || !deltas || !hsteploss || !loss || !stats || !partial || !ticket || b <= 0 || t < 2 || n <= 0)
         return fail(-1, "sur_tbptt_delta_loss: bad argument (need B > 0, T >= 2, N > 0)");
     if (!(delta != 0.0f) || !(stdv > 0.0f)) return fail(-1, "sur_tbptt_delta_loss: delta must be non-zero and std positive");
+    int nsplit = (b * n + LOSS_UNROLL * TPB - 1) / (LOSS_UNROLL * TPB);
+    nsplit = nsplit < 1 ? 1 : (nsplit > LOSS_MAX_SPLIT ? LOSS_MAX_SPLIT : nsplit);
     return launch_checked([&] {
-        hipLaunchKernelGGL(delta_loss_kernel, dim3(t), dim3(TPB), 0, (hipStream_t)stream, states, d_all, b, t, n, delta, mean,
+        hipLaunchKernelGGL(delta_loss_kernel, dim3(t, nsplit), dim3(TPB), 0, (hipStream_t)stream, states, d_all, b, t, n, delta, mean,
                            stdv, deltas, dd_all, hsteploss, loss, stats, partial, ticket);
     }, "delta_loss");
 }

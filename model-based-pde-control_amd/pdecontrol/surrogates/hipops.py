@@ -128,7 +128,9 @@ class _Pack:
             self.dirty = False
 
 
-ENCODER_ROWS = 256  # one partial row per workgroup of the encoder backward (>= #CUs keeps every CU busy)
+# one partial row per workgroup of the encoder backward: two workgroups per CU (the kernel is built for 2 waves per
+# SIMD) hide each other's dependent-phase latency
+ENCODER_ROWS = 512
 
 
 def _encoder_pack(convnet, n):
@@ -378,6 +380,7 @@ class _DeltaLossFn(torch.autograd.Function):
         new = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)
         deltas, hstep, loss, stats = new(b, t - 1, 1, n), new(t - 1), new(), new(4)
         dd = torch.empty_like(d_all) if ctx.needs_input_grad[0] else None
+        ctx.set_materialize_grads(False)
         partial, ticket = scratch
         _check(load().sur_tbptt_delta_loss(_stream(), _p(states), _p(d_all), b, t, n, delta, mean, stdv, _p(deltas), _p(dd),
                                            _p(hstep), _p(loss), _p(stats), _p(partial), _p(ticket)))
@@ -398,7 +401,7 @@ def fused_delta_loss(surrogate, d_all, states, delta, mean, stdv):
     t = d_all.shape[0]
     scratch = owner.loss_scratch.get(t)
     if scratch is None:
-        scratch = (torch.empty(5 * t, device=d_all.device, dtype=torch.float64),
+        scratch = (torch.empty(40 * t, device=d_all.device, dtype=torch.float64),
                    torch.zeros(1, device=d_all.device, dtype=torch.int32))
         owner.loss_scratch[t] = scratch
     return _DeltaLossFn.apply(d_all, states, float(delta), float(mean), float(stdv), scratch)
@@ -480,10 +483,11 @@ class _Fork:
 
     def __init__(self, stream):
         self.main = torch.cuda.current_stream(stream.device)
-        self.stream = stream if _INNER_FORKS else self.main
+        self.forked = _INNER_FORKS
+        self.stream = stream if self.forked else self.main
 
     def __enter__(self):
-        if self.stream is not self.main:
+        if self.forked:
             self.stream.wait_stream(self.main)
         self.ctx = torch.cuda.stream(self.stream)
         self.ctx.__enter__()
@@ -493,7 +497,7 @@ class _Fork:
         self.ctx.__exit__(*exc)
 
     def join(self):
-        if self.stream is not self.main:
+        if self.forked:
             self.main.wait_stream(self.stream)
 
 
@@ -574,8 +578,7 @@ class _TBPTTFn(torch.autograd.Function):
         owner.state_enc.ensure_rows(sum(enc_rows))
         owner.refresh_partials()
         streams = _side_streams(owner, dev, nchunks)
-        main = torch.cuda.current_stream(dev)
-        forks, row0 = [], 0
+        forks, chunk_done, row0 = [], [], 0
         for c, (k0, k1) in enumerate(bounds):
             fork = _Fork(streams[c])
             with fork:
@@ -584,18 +587,21 @@ class _TBPTTFn(torch.autograd.Function):
                                               _p(h0s[c]), _p(c0s[c]), _p(h_alls[c]), _p(c_alls[c]), _p(dd_all[k0:k1]), None,
                                               None, None, k1 - k0, min(seeds[c].shape[0], k1 - k0), b,
                                               _p(dxlat_all[k0:k1]), _p(dlst), None, None, c * b, _p(saveds[c])))
-                if fork.stream is not main:
-                    # the action-encoder backward below only needs this chunk's dxlat: it must not wait for the
+                if fork.forked:
+                    # the action-encoder backward below only needs the chunks' dxlat: it must not wait for the
                     # state-encoder backward that follows on this side stream
                     done = torch.cuda.Event()
                     done.record(fork.stream)
-                    main.wait_event(done)
+                    chunk_done.append(done)
                 m = lstates[c].shape[0] * b
                 _check(lib.sur_encoder_backward(_stream(), ctypes.byref(owner.state_enc.c), _p(seeds[c]), _p(dlst), m, None,
                                                 row0, enc_rows[c]))
                 dlst.record_stream(fork.stream)
             row0 += enc_rows[c]
             forks.append(fork)
+        main = torch.cuda.current_stream(dev)
+        for done in chunk_done:
+            main.wait_event(done)
         _check(lib.sur_encoder_backward(_stream(), ctypes.byref(owner.action_enc.c), _p(actions_t), _p(dxlat_all),
                                         t_total * b, None, 0, min(ENCODER_ROWS, owner.action_enc.c.rows)))
         for fork in forks:

@@ -19,6 +19,11 @@ lib.sur_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
 m = build_module(dev)
 batch = synthetic_batch(B=64, device=dev)
 def fwd_bwd():
+    with hipops.inner_forks(False):   # one kernel at a time: the stamp buffer is shared by every launch
+        _fwd_bwd()
+
+
+def _fwd_bwd():
     for p in m.surrogate.parameters():
         if p.grad is not None:
             p.grad.zero_()
@@ -34,11 +39,15 @@ buf = (ctypes.c_longlong * 32)()
 lib.sur_debug_stamps(buf, 0)
 names = {1: "fwd gates gemm", 2: "fwd gate activations", 3: "fwd deconv0", 4: "fwd LN0+silu", 5: "fwd deconv1",
          6: "fwd LN1+silu", 7: "fwd conv7", 8: "fwd LN2+silu", 9: "fwd conv5", 11: "fwd step output store",
-         21: "bwd: recompute forward (incl. the fwd phases above)", 22: "bwd: dd assembly", 23: "bwd: decoder backward",
+         12: "bwd dec: conv5 weight grad", 13: "bwd dec: conv5 data grad", 14: "bwd dec: LN2 bwd",
+         15: "bwd dec: conv7 weight grad", 16: "bwd dec: conv7 data grad", 17: "bwd dec: LN1 bwd",
+         18: "bwd dec: deconv1 weight grad", 19: "bwd dec: deconv1 data grad", 26: "bwd dec: LN0 bwd",
+         27: "bwd dec: deconv0 weight grad", 23: "bwd dec: deconv0 data grad",
+         20: "bwd: load step inputs / commit prefetch", 21: "bwd: recompute forward or issue prefetch", 22: "bwd: dd assembly",
          24: "bwd: cell elementwise", 25: "bwd: cell GEMMs (dx, dh, gWx, gWh)"}
 vals = list(buf)
 print("one training step (forward + backward), workgroup 0, shader-clock cycles per rollout step:")
-print("(phases 1-9 accumulate over BOTH chunk_fwd and the recompute inside chunk_bwd: 40 executions)")
-for i, n in names.items():
-    per = vals[i] / (40 if i <= 9 else 20)
+print("(with saved activations the backward kernel does not re-run phases 1-9: 20 executions each)")
+for i, n in sorted(names.items()):
+    per = vals[i] / (20 if (i <= 9 or i >= 12) else 20)
     print(f"  {n:55s} {per:9.0f}")
