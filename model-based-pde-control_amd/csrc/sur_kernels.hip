@@ -57,6 +57,31 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+template <int CTRL>
+__device__ __forceinline__ float dpp_rot(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+
+// sums of a and b over aligned groups of `lpc` lanes (16, 32 or 64); every lane gets both totals
+__device__ __forceinline__ void group_sum2(float& a, float& b, int lpc) {
+    a += dpp_rot<0x128>(a);  // row_ror:8
+    b += dpp_rot<0x128>(b);
+    a += dpp_rot<0x124>(a);  // row_ror:4
+    b += dpp_rot<0x124>(b);
+    a += dpp_rot<0x122>(a);  // row_ror:2
+    b += dpp_rot<0x122>(b);
+    a += dpp_rot<0x121>(a);  // row_ror:1
+    b += dpp_rot<0x121>(b);
+    if (lpc >= 32) {
+        a += __shfl_xor(a, 16, 64);
+        b += __shfl_xor(b, 16, 64);
+    }
+    if (lpc >= 64) {
+        a += __shfl_xor(a, 32, 64);
+        b += __shfl_xor(b, 32, 64);
+    }
+}
+
 __device__ __forceinline__ float sigmoid_(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ __forceinline__ int wrapi(int j, int n) { return j < 0 ? j + n : (j >= n ? j - n : j); }
 
@@ -245,31 +270,51 @@ template <int K>
 __device__ void conv_bwd_weight(const float* dout, int cout, const float* in, int cin, int hin, int stride, int pad,
                                 float* gW, float* gb, WaveSet ws = WaveSet{0, 1 << 20}, bool sync = true) {
     const int hout = hin / stride, ncols = cin * K;
-    if (gb) {
-        for (int o = threadIdx.x; o < cout; o += blockDim.x) {
-            float a0 = 0.0f, a1 = 0.0f;
-            for (int p = 0; p < hout; p += 2) {
-                a0 += dout[o * hout + p];
-                a1 += dout[o * hout + p + 1];
-            }
-            gb[o] += a0 + a1;
-        }
-    }
     if (cout == 1) {
-        for (int idx = threadIdx.x; idx < ncols; idx += blockDim.x) {
-            const int ci = idx / K, k = idx - ci * K;
-            const float* row = in + ci * hin;
-            float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
-            for (int p = 0; p < hout; p += 4) {
-                a0 = fmaf(dout[p + 0], row[wrapi((p + 0) * stride + k - pad, hin)], a0);
-                a1 = fmaf(dout[p + 1], row[wrapi((p + 1) * stride + k - pad, hin)], a1);
-                a2 = fmaf(dout[p + 2], row[wrapi((p + 2) * stride + k - pad, hin)], a2);
-                a3 = fmaf(dout[p + 3], row[wrapi((p + 3) * stride + k - pad, hin)], a3);
+        // ncols + 1 dot products of length hout (the weight taps and the bias): one per 16-lane group, positions
+        // strided over the group's lanes, partial sums folded with DPP row rotations.  (One thread per dot product
+        // with a serial loop over hout cost 8 k cycles per call: the slowest phase of the decoder backward.)
+        const int group = threadIdx.x >> 4, gl = threadIdx.x & 15, ngroups = blockDim.x >> 4;
+        const int nout = ncols + (gb ? 1 : 0);
+        for (int idx0 = 0; idx0 < nout; idx0 += ngroups) {
+            const int idx = idx0 + group;
+            float a0 = 0.0f, a1 = 0.0f;
+            if (idx < ncols) {
+                const int ci = idx / K, k = idx - ci * K;
+                const float* row = in + ci * hin;
+                for (int p = gl; p < hout; p += 32) {
+                    a0 = fmaf(dout[p], row[wrapi(p * stride + k - pad, hin)], a0);
+                    if (p + 16 < hout) a1 = fmaf(dout[p + 16], row[wrapi((p + 16) * stride + k - pad, hin)], a1);
+                }
+            } else if (idx == ncols && gb) {
+                for (int p = gl; p < hout; p += 32) {
+                    a0 += dout[p];
+                    if (p + 16 < hout) a1 += dout[p + 16];
+                }
             }
-            gW[idx] += (a0 + a1) + (a2 + a3);
+            group_sum2(a0, a1, 16);
+            if (gl == 0) {
+                if (idx < ncols) gW[idx] += a0 + a1;
+                else if (idx == ncols && gb) gb[0] += a0 + a1;
+            }
         }
         if (sync) __syncthreads();
         return;
+    }
+    if (gb) {
+        // bias gradient: one 16-lane group per output channel
+        const int group = threadIdx.x >> 4, gl = threadIdx.x & 15, ngroups = blockDim.x >> 4;
+        for (int o0 = 0; o0 < cout; o0 += ngroups) {
+            const int o = o0 + group;
+            float a0 = 0.0f, a1 = 0.0f;
+            if (o < cout)
+                for (int p = gl; p < hout; p += 32) {
+                    a0 += dout[o * hout + p];
+                    if (p + 16 < hout) a1 += dout[o * hout + p + 16];
+                }
+            group_sum2(a0, a1, 16);
+            if (gl == 0 && o < cout) gb[o] += a0 + a1;
+        }
     }
     struct St { const float* row; int off; };
     gemm_pos(ws, sync, cout, ncols, hout, dout, hout,
@@ -345,31 +390,6 @@ __device__ void deconv_bwd_weight(const float* dout, int cout, const float* in, 
 // H/LPC activated values in registers; mean and E[y^2] are reduced TOGETHER (two interleaved chains)
 // with DPP row rotations inside 16-lane rows and one ds_bpermute per doubling beyond a row.
 // ---------------------------------------------------------------------------------------------
-template <int CTRL>
-__device__ __forceinline__ float dpp_rot(float v) {
-    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, false));
-}
-
-// sums of a and b over aligned groups of `lpc` lanes (16, 32 or 64); every lane gets both totals
-__device__ __forceinline__ void group_sum2(float& a, float& b, int lpc) {
-    a += dpp_rot<0x128>(a);  // row_ror:8
-    b += dpp_rot<0x128>(b);
-    a += dpp_rot<0x124>(a);  // row_ror:4
-    b += dpp_rot<0x124>(b);
-    a += dpp_rot<0x122>(a);  // row_ror:2
-    b += dpp_rot<0x122>(b);
-    a += dpp_rot<0x121>(a);  // row_ror:1
-    b += dpp_rot<0x121>(b);
-    if (lpc >= 32) {
-        a += __shfl_xor(a, 16, 64);
-        b += __shfl_xor(b, 16, 64);
-    }
-    if (lpc >= 64) {
-        a += __shfl_xor(a, 32, 64);
-        b += __shfl_xor(b, 32, 64);
-    }
-}
-
 constexpr int LN_MAX_EPL = 4;  // H <= 256
 
 // out = LayerNorm_H(act(pre)) * gamma[p] + beta[p], act = SiLU or identity
@@ -1170,6 +1190,7 @@ chunk_bwd_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, con
                 gemm_taps<3, 4>(w_dx, false, ca, hq, sx, tap_col, [&](int m, int j, float v) {
                     if (m < ca) dxp[m * hq + j] = v;
                 });
+                STAMP(28);
                 const float* wh = w[SUR_ST_WHI];
                 const GemmSeg sh[4] = {{wh, 3, cs * 3, L.dgates, hq, cs},
                                        {wh + gate_stride, 3, cs * 3, L.dgates + s, hq, cs},
@@ -1179,6 +1200,7 @@ chunk_bwd_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, con
                 gemm_taps<3, 4>(w_dh, false, cs, hq, sh, tap_col, [&](int m, int j, float v) {
                     if (m < cs) dhp[m * hq + j] = v;
                 });
+                STAMP(29);
             }
             // weight gradients, all gates in one GEMM each: rows m = (gate, o)
             struct St { const float* row; int off; };
@@ -1195,6 +1217,7 @@ chunk_bwd_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, con
                                  gx[gt * gate_stride + o * ncols + n] += v;
                              }
                          });
+                STAMP(30);
                 float* gh = g[SUR_ST_WHI];
                 const float* hin_ = L.h;
                 const int ncols_h = cs * 3;
@@ -1207,6 +1230,7 @@ chunk_bwd_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, con
                                  gh[gt * gate_stride + o * ncols_h + n] += v;
                              }
                          });
+                STAMP(31);
                 float* gbx = g[SUR_ST_BXI];
                 for (int idx = threadIdx.x; idx < 4 * cs; idx += blockDim.x) {
                     const int gt = idx / cs, o = idx - gt * cs;

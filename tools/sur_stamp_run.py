@@ -43,8 +43,10 @@ names = {1: "fwd gates gemm", 2: "fwd gate activations", 3: "fwd deconv0", 4: "f
          15: "bwd dec: conv7 weight grad", 16: "bwd dec: conv7 data grad", 17: "bwd dec: LN1 bwd",
          18: "bwd dec: deconv1 weight grad", 19: "bwd dec: deconv1 data grad", 26: "bwd dec: LN0 bwd",
          27: "bwd dec: deconv0 weight grad", 23: "bwd dec: deconv0 data grad",
+         28: "bwd cell: dx GEMM (alone)", 29: "bwd cell: dh GEMM (alone)", 30: "bwd cell: gWx GEMM (alone)",
+         31: "bwd cell: gWh GEMM (alone)", 25: "bwd cell: gate bias grads + closing barrier",
          20: "bwd: load step inputs / commit prefetch", 21: "bwd: recompute forward or issue prefetch", 22: "bwd: dd assembly",
-         24: "bwd: cell elementwise", 25: "bwd: cell GEMMs (dx, dh, gWx, gWh)"}
+         24: "bwd: cell elementwise"}
 vals = list(buf)
 print("one training step (forward + backward), workgroup 0, shader-clock cycles per rollout step:")
 print("(with saved activations the backward kernel does not re-run phases 1-9: 20 executions each)")
