@@ -845,19 +845,31 @@ delta_loss_kernel(const float* __restrict__ states, const float* __restrict__ d_
     __syncthreads();
     if (!last) return;
     __threadfence();
-    // fixed-order reduction of the (T-1) x nsplit partial sums by the workgroup that arrived last
-    const volatile double* part = partial;
+    // fixed-order reduction of the (T-1) x nsplit partial sums by the workgroup that arrived last.  The partials are
+    // fetched with relaxed device-scope atomic loads, one partial per thread, so the loads overlap (a serial loop
+    // of volatile loads cost ~20 us here).
+    auto peek = [&](size_t i) { return __hip_atomic_load(partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     __shared__ double tsum[LOSS_NSUM];
+    __shared__ double stage[LOSS_NSUM][TPB];
     for (int tt = threadIdx.x; tt < T - 1; tt += blockDim.x) {
         double se = 0.0;
-        for (int y = 0; y < nsplit; ++y) se += part[((size_t)tt * nsplit + y) * LOSS_NSUM];
+        for (int y = 0; y < nsplit; ++y) se += peek(((size_t)tt * nsplit + y) * LOSS_NSUM);
         hsteploss[tt] = (float)(se / per_t);
     }
-    if (threadIdx.x < LOSS_NSUM) {
-        double tot = 0.0;
-        for (int q = 0; q < (T - 1) * nsplit; ++q) tot += part[(size_t)q * LOSS_NSUM + threadIdx.x];
-        tsum[threadIdx.x] = tot;
+    const int nq = (T - 1) * nsplit;
+    double tot = 0.0;
+    for (int q0 = 0; q0 < nq; q0 += TPB) {
+        const int q = q0 + threadIdx.x;
+#pragma unroll
+        for (int j = 0; j < LOSS_NSUM; ++j) stage[j][threadIdx.x] = q < nq ? peek((size_t)q * LOSS_NSUM + j) : 0.0;
+        __syncthreads();
+        if (threadIdx.x < LOSS_NSUM) {
+            const int lim = nq - q0 < TPB ? nq - q0 : TPB;
+            for (int i = 0; i < lim; ++i) tot += stage[threadIdx.x][i];
+        }
+        __syncthreads();
     }
+    if (threadIdx.x < LOSS_NSUM) tsum[threadIdx.x] = tot;
     __syncthreads();
     if (threadIdx.x == 0) {
         *loss = (float)(tsum[0] / count);
