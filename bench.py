@@ -73,9 +73,39 @@ def cpu_baseline(E, N, L, target_seconds=12.0):
     t0 = time.perf_counter()
     ko.step(u0, phi, L / N, DT, nsub, nthreads=cores)
     dt = time.perf_counter() - t0
-    return {"value": E * nsub / dt, "unit": "sub-steps/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/ks_oracle.c (bit-exact C restatement of the reference stepper), {E} envs x {nsub} "
-                      f"sub-steps, N={N}, OpenMP over envs, {dt:.1f} s"}
+    out = {"value": E * nsub / dt, "unit": "sub-steps/s", "cores": cores, "kind": "port",
+           "sample": f"oracle/ks_oracle.c (bit-exact C restatement of the reference stepper), {E} envs x {nsub} "
+                     f"sub-steps, N={N}, OpenMP over envs, {dt:.1f} s"}
+    # SURVEY 8(d) baseline (A): the reference's own call structure (per-env object, Python loop over sub-steps,
+    # 16 scipy convolve1d + a torch round trip per sub-step), one env on one core
+    try:
+        n_py = 1500
+        t0 = time.perf_counter()
+        ko.step_scipy_structured(u0[0], phi[0].astype(np.float64), L / N, DT, n_py)
+        dt_py = time.perf_counter() - t0
+        out["reference_call_structure"] = {"value": n_py / dt_py, "unit": "sub-steps/s per core", "cores": 1,
+                                           "sample": f"1 env x {n_py} sub-steps through scipy.ndimage.convolve1d + torch.norm, "
+                                                     f"{dt_py:.1f} s; the reference runs one such process per env"}
+    except Exception as exc:  # scipy / torch CPU missing must not lose the baseline
+        out["reference_call_structure"] = {"error": f"{type(exc).__name__}: {exc}"}
+    return out
+
+
+def measured_hbm_copy_gbs(dev, mib=1024, reps=10):
+    """Device-to-device copy rate of this box (read + write bytes per second), SURVEY 8(d): the measured companion of
+    the nominal 8 TB/s the roofline fraction is quoted against."""
+    n = mib * (1 << 20) // 4
+    a = torch.empty(n, dtype=torch.float32, device=dev).normal_()
+    b = torch.empty_like(a)
+    for _ in range(2):
+        b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    return 2.0 * a.numel() * 4 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
 def measure_secondary(kspde, local_rank, dev, name, mode, steps=20, warmup=3):
@@ -244,6 +274,12 @@ def main():
                           "flops_per_point_substep": FLOPS_PER_POINT_SUBSTEP},
         },
     }
+    if rank == 0 and n_gpus == 1:
+        try:
+            out["roofline"]["hbm_copy_measured"] = {"value": measured_hbm_copy_gbs(dev), "unit": "GB/s",
+                                                    "what": "1 GiB device-to-device copy, read + write bytes"}
+        except Exception as exc:
+            out["roofline"]["hbm_copy_measured"] = {"error": f"{type(exc).__name__}: {exc}"}
     if rank == 0 and n_gpus == 1 and args.workload == "c2":
         # secondary workload in the same run: BASELINE configs[2] (4096 x 256, L = 88) -- not the headline value
         try:
