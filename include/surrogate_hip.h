@@ -69,12 +69,17 @@ typedef struct sur_chunk_params {
     int rows;
 } sur_chunk_params;
 
-int sur_encoder_forward(void* stream, const sur_encoder_params* p, const float* x, int m, float* z);
+/* Floats per sample of the forward intermediates sur_encoder_forward can save for sur_encoder_backward (0 = this
+ * geometry has no saved-activation path).  With `saved` [M, sur_encoder_saved_floats] the backward kernel loads
+ * the three blocks' intermediates instead of recomputing them (a third of its time); results are bit-identical. */
+int sur_encoder_saved_floats(const sur_encoder_params* p);
+int sur_encoder_forward(void* stream, const sur_encoder_params* p, const float* x, int m, float* z,
+                        float* saved /* may be NULL */);
 /* dx may be NULL (raw data input).  Accumulates parameter gradients into rows
  * [row_base, row_base + row_count) of p->partial (one row per workgroup; launches that may run
  * concurrently on different streams must be given disjoint row ranges). */
 int sur_encoder_backward(void* stream, const sur_encoder_params* p, const float* x, const float* dz, int m,
-                         float* dx, int row_base, int row_count);
+                         float* dx, int row_base, int row_count, const float* saved /* or NULL = recompute */);
 int sur_flush_encoder_grads(void* stream, const sur_encoder_params* p);
 
 /* Floats per (step, sample) of the forward intermediates sur_chunk_forward can save for sur_chunk_backward

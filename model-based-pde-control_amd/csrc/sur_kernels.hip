@@ -701,8 +701,28 @@ __device__ void enc_layout(const sur_encoder_params& p, float* lds, bool backwar
     L.end = cur;
 }
 
+// floats of one sample's forward intermediates (everything after the input in the LDS layout), as enc_fwd_kernel can
+// save them for enc_bwd_kernel
+__host__ __device__ inline int enc_saved_floats(const sur_encoder_params& p) { return enc_act_floats(p, false) - p.c[0] * p.n; }
+
+// n4 float4 from global to LDS with all of a thread's loads of a round in flight before the first store
+__device__ __forceinline__ void lds_load_v4(float* dst, const float* __restrict__ src, int n4) {
+    constexpr int U = 4;
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+    float4* d4 = reinterpret_cast<float4*>(dst);
+    for (int i0 = threadIdx.x; i0 < n4; i0 += U * TPB) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = s4[i0 + u * TPB < n4 ? i0 + u * TPB : i0];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (i0 + u * TPB < n4) d4[i0 + u * TPB] = v[u];
+    }
+    __syncthreads();
+}
+
 __global__ void __launch_bounds__(TPB) enc_fwd_kernel(const sur_encoder_params p, const float* __restrict__ x, int m_total,
-                                                      float* __restrict__ z) {
+                                                      float* __restrict__ z, float* __restrict__ saved) {
     extern __shared__ __align__(16) float lds[];
     EncLayout L;
     enc_layout(p, lds, false, L);
@@ -713,6 +733,12 @@ __global__ void __launch_bounds__(TPB) enc_fwd_kernel(const sur_encoder_params p
         lds_load(L.rb[0].in, x + (size_t)m * nin, nin);
 #pragma unroll
         for (int b = 0; b < 3; ++b) rb_forward(L.rb[b], v.w + b * SUR_RB_NPARAM);
+        if (saved) {  // every intermediate of the three blocks: the backward kernel then skips its forward recomputation
+            const int n4 = enc_saved_floats(p) >> 2;
+            float4* dst = reinterpret_cast<float4*>(saved + (size_t)m * (n4 << 2));
+            const float4* src = reinterpret_cast<const float4*>(L.rb[0].skip);
+            for (int i = threadIdx.x; i < n4; i += blockDim.x) dst[i] = src[i];
+        }
         lds_store(z + (size_t)m * nout, L.rb[2].out, nout);
     }
 }
@@ -724,7 +750,7 @@ __global__ void __launch_bounds__(TPB) enc_fwd_kernel(const sur_encoder_params p
 #endif
 __global__ void __launch_bounds__(TPB, ENC_BWD_OCC) enc_bwd_kernel(const sur_encoder_params p, const float* __restrict__ x,
                                                       const float* __restrict__ dz, int m_total, float* __restrict__ dx,
-                                                      int grads_in_lds, int row_base) {
+                                                      int grads_in_lds, int row_base, const float* __restrict__ saved) {
     extern __shared__ __align__(16) float lds[];
     STAMP(32);
     EncLayout L;
@@ -741,8 +767,13 @@ __global__ void __launch_bounds__(TPB, ENC_BWD_OCC) enc_bwd_kernel(const sur_enc
     for (int m = blockIdx.x; m < m_total; m += gridDim.x) {
         lds_load(L.rb[0].in, x + (size_t)m * nin, nin);
         STAMP(35);
+        if (saved) {  // the second workgroup resident on this CU covers the load latency
+            const int nsv = enc_saved_floats(p);
+            lds_load_v4(L.rb[0].skip, saved + (size_t)m * nsv, nsv >> 2);
+        } else {
 #pragma unroll
-        for (int b = 0; b < 3; ++b) rb_forward(L.rb[b], v.w + b * SUR_RB_NPARAM);
+            for (int b = 0; b < 3; ++b) rb_forward(L.rb[b], v.w + b * SUR_RB_NPARAM);
+        }
         STAMP(36);
         lds_load(L.dA, dz + (size_t)m * nout, nout);
         STAMP(37);
@@ -1352,20 +1383,30 @@ int sur_debug_stamps(long long* out64, int reset) {
 }
 #endif
 
-int sur_encoder_forward(void* stream, const sur_encoder_params* p, const float* x, int m, float* z) {
+int sur_encoder_saved_floats(const sur_encoder_params* p) {
+    if (!p) return 0;
+    const int total = enc_saved_floats(*p);
+    return ((total & 3) || ((p->c[0] * p->n) & 3)) ? 0 : total;  // float4 granularity of the block and of its LDS position
+}
+
+int sur_encoder_forward(void* stream, const sur_encoder_params* p, const float* x, int m, float* z, float* saved) {
     if (!p || !x || !z || m <= 0) return fail(-1, "sur_encoder_forward: bad argument");
+    if (saved && sur_encoder_saved_floats(p) == 0)
+        return fail(-4, "sur_encoder_forward: this geometry has no saved-activation path (pass saved = NULL)");
     if (p->n > 64 * LN_MAX_EPL * p->stride[0]) return fail(-4, "sur_encoder_forward: N = %d too wide for the fused LayerNorm", p->n);
     const int psize = psize_of<SUR_ENC_NPARAM>(p->size);
     const size_t lds = sizeof(float) * (enc_act_floats(*p, false) + psize);
     if (int rc = set_lds(enc_fwd_kernel, lds, "encoder forward")) return rc;
     const int grid = m < 1024 ? m : 1024;
-    return launch_checked([&] { hipLaunchKernelGGL(enc_fwd_kernel, dim3(grid), dim3(TPB), lds, (hipStream_t)stream, *p, x, m, z); },
+    return launch_checked([&] { hipLaunchKernelGGL(enc_fwd_kernel, dim3(grid), dim3(TPB), lds, (hipStream_t)stream, *p, x, m, z, saved); },
                           "enc_fwd");
 }
 
 int sur_encoder_backward(void* stream, const sur_encoder_params* p, const float* x, const float* dz, int m, float* dx,
-                         int row_base, int row_count) {
+                         int row_base, int row_count, const float* saved) {
     if (!p || !x || !dz || m <= 0) return fail(-1, "sur_encoder_backward: bad argument");
+    if (saved && sur_encoder_saved_floats(p) == 0)
+        return fail(-4, "sur_encoder_backward: this geometry has no saved-activation path (pass saved = NULL)");
     if (!p->partial || row_count <= 0 || row_base < 0 || row_base + row_count > p->rows)
         return fail(-1, "sur_encoder_backward: partial rows [%d, %d) outside the buffer of %d rows", row_base,
                     row_base + row_count, p ? p->rows : 0);
@@ -1377,7 +1418,7 @@ int sur_encoder_backward(void* stream, const sur_encoder_params* p, const float*
     const int grid = m < row_count ? m : row_count;
     return launch_checked([&] {
         hipLaunchKernelGGL(enc_bwd_kernel, dim3(grid), dim3(TPB), lds, (hipStream_t)stream, *p, x, dz, m, dx, grads_in_lds,
-                           row_base);
+                           row_base, saved);
     }, "enc_bwd");
 }
 

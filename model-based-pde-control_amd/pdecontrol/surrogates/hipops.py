@@ -40,8 +40,9 @@ class ChunkParams(ctypes.Structure):
 
 _EP, _CP, _i = ctypes.POINTER(EncoderParams), ctypes.POINTER(ChunkParams), ctypes.c_int
 SYMBOLS = (
-    ("sur_encoder_forward", [_fp, _EP, _fp, _i, _fp]),
-    ("sur_encoder_backward", [_fp, _EP, _fp, _fp, _i, _fp, _i, _i]),
+    ("sur_encoder_saved_floats", [_EP]),
+    ("sur_encoder_forward", [_fp, _EP, _fp, _i, _fp, _fp]),
+    ("sur_encoder_backward", [_fp, _EP, _fp, _fp, _i, _fp, _i, _i, _fp]),
     ("sur_flush_encoder_grads", [_fp, _EP]),
     ("sur_chunk_saved_floats", [_CP]),
     ("sur_chunk_forward", [_fp, _CP, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _fp, _fp, _fp, _fp, _fp]),
@@ -297,9 +298,10 @@ class _EncoderFn(torch.autograd.Function):
         for s in pack.c.stride:
             h //= s
         z = torch.empty((m, pack.c.c[3], h), device=x.device, dtype=torch.float32)
-        _check(load().sur_encoder_forward(_stream(), ctypes.byref(pack.c), _p(x), m, _p(z)))
+        saved = _encoder_saved_buffer(pack, m, x.device) if any(ctx.needs_input_grad) else None
+        _check(load().sur_encoder_forward(_stream(), ctypes.byref(pack.c), _p(x), m, _p(z), _p(saved)))
         ctx.save_for_backward(x)
-        ctx.pack, ctx.owner, ctx.need_dx = pack, owner, x.requires_grad
+        ctx.pack, ctx.owner, ctx.need_dx, ctx.fwd_saved = pack, owner, x.requires_grad, saved
         return z
 
     @staticmethod
@@ -307,13 +309,20 @@ class _EncoderFn(torch.autograd.Function):
         (x,) = ctx.saved_tensors
         dx = torch.empty_like(x) if ctx.need_dx else None
         _check(load().sur_encoder_backward(_stream(), ctypes.byref(ctx.pack.c), _p(x), _p(dz.contiguous()), x.shape[0],
-                                           _p(dx), 0, min(ENCODER_ROWS, ctx.pack.c.rows)))
+                                           _p(dx), 0, min(ENCODER_ROWS, ctx.pack.c.rows), _p(ctx.fwd_saved)))
+        ctx.fwd_saved = None
         ctx.pack.dirty = True
         ctx.owner.schedule_flush()
         return dx, None, None, None
 
 
 SAVE_ACTIVATIONS = True   # False: the backward kernel recomputes each step's forward (bit-identical, slower)
+
+
+def _encoder_saved_buffer(pack, m, device):
+    """[M, F] buffer for the encoder's forward intermediates (None: no saved-activation path for this geometry)."""
+    f = load().sur_encoder_saved_floats(ctypes.byref(pack.c)) if SAVE_ACTIVATIONS else 0
+    return torch.empty((m, f), device=device, dtype=torch.float32) if f > 0 else None
 
 
 def _saved_buffer(pack, k, b, device):
@@ -525,10 +534,15 @@ class _TBPTTFn(torch.autograd.Function):
         lactions_t = torch.empty((t_total, b, ca, hq), device=dev, dtype=torch.float32)
         fork = _Fork(side)
         with fork:   # all T action encodings in one launch, beside the chunk-0 state encoding
+            asaved = _encoder_saved_buffer(owner.action_enc, t_total * b, dev)
             _check(lib.sur_encoder_forward(_stream(), ctypes.byref(owner.action_enc.c), _p(actions_t), t_total * b,
-                                           _p(lactions_t)))
+                                           _p(lactions_t), _p(asaved)))
+            if asaved is not None:
+                asaved.record_stream(torch.cuda.current_stream(dev))
         lstates = [torch.empty((tau, b, cs, hq), device=dev, dtype=torch.float32)]
-        _check(lib.sur_encoder_forward(_stream(), ctypes.byref(owner.state_enc.c), _p(states_t0), tau * b, _p(lstates[0])))
+        ssaved = [_encoder_saved_buffer(owner.state_enc, tau * b, dev)]
+        _check(lib.sur_encoder_forward(_stream(), ctypes.byref(owner.state_enc.c), _p(states_t0), tau * b, _p(lstates[0]),
+                                       _p(ssaved[0])))
         fork.join()
 
         tm = surrogate.transition_model
@@ -541,7 +555,9 @@ class _TBPTTFn(torch.autograd.Function):
             if c > 0:   # later chunks restart from the previous chunk's last prediction (gradients cut)
                 seeds.append(out_all[k0 - 1:k0])
                 lst = torch.empty((1, b, cs, hq), device=dev, dtype=torch.float32)
-                _check(lib.sur_encoder_forward(_stream(), ctypes.byref(owner.state_enc.c), _p(seeds[c]), b, _p(lst)))
+                ssaved.append(_encoder_saved_buffer(owner.state_enc, b, dev))
+                _check(lib.sur_encoder_forward(_stream(), ctypes.byref(owner.state_enc.c), _p(seeds[c]), b, _p(lst),
+                                               _p(ssaved[c])))
                 lstates.append(lst)
                 h0s.append(h_alls[-1][-1])
                 c0s.append(c_alls[-1][-1])
@@ -557,7 +573,7 @@ class _TBPTTFn(torch.autograd.Function):
             c_alls.append(c_all)
             saveds.append(saved)
         ctx.owner, ctx.bounds, ctx.dims = owner, bounds, (b, t_total, n, nchunks)
-        ctx.saved = (actions_t, lactions_t, seeds, lstates, h0s, c0s, h_alls, c_alls, saveds)
+        ctx.saved = (actions_t, lactions_t, seeds, lstates, h0s, c0s, h_alls, c_alls, saveds, asaved, ssaved)
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(out_all)
         return d_all, out_all, h_alls[-1][-1], c_alls[-1][-1]
@@ -566,7 +582,7 @@ class _TBPTTFn(torch.autograd.Function):
     def backward(ctx, dd_all, _dout, _dh, _dc):
         owner, bounds = ctx.owner, ctx.bounds
         b, t_total, n, nchunks = ctx.dims
-        actions_t, lactions_t, seeds, lstates, h0s, c0s, h_alls, c_alls, saveds = ctx.saved
+        actions_t, lactions_t, seeds, lstates, h0s, c0s, h_alls, c_alls, saveds, asaved, ssaved = ctx.saved
         lib = load()
         dev = actions_t.device
         if dd_all is None:
@@ -595,7 +611,7 @@ class _TBPTTFn(torch.autograd.Function):
                     chunk_done.append(done)
                 m = lstates[c].shape[0] * b
                 _check(lib.sur_encoder_backward(_stream(), ctypes.byref(owner.state_enc.c), _p(seeds[c]), _p(dlst), m, None,
-                                                row0, enc_rows[c]))
+                                                row0, enc_rows[c], _p(ssaved[c])))
                 dlst.record_stream(fork.stream)
             row0 += enc_rows[c]
             forks.append(fork)
@@ -603,7 +619,7 @@ class _TBPTTFn(torch.autograd.Function):
         for done in chunk_done:
             main.wait_event(done)
         _check(lib.sur_encoder_backward(_stream(), ctypes.byref(owner.action_enc.c), _p(actions_t), _p(dxlat_all),
-                                        t_total * b, None, 0, min(ENCODER_ROWS, owner.action_enc.c.rows)))
+                                        t_total * b, None, 0, min(ENCODER_ROWS, owner.action_enc.c.rows), _p(asaved)))
         for fork in forks:
             fork.join()
         for pack in owner.packs:
