@@ -53,3 +53,36 @@ def test_fused_surrogate_requires_library(monkeypatch):
     monkeypatch.setattr(hipops, "_lib", None)
     with pytest.raises(hipops.SurrogateHipError):
         hipops.load()
+
+
+def test_surrogate_abi_rejects_bad_arguments_before_touching_the_device():
+    """Argument validation of libsurrogate_hip.so happens on the host: negative status + a message, no HIP call."""
+    lib_path = os.path.join(LIBDIR, "libsurrogate_hip.so")
+    if not os.path.exists(lib_path):
+        pytest.skip("libsurrogate_hip.so not built")
+    from pdecontrol.surrogates import hipops
+    lib = hipops.load()
+    enc, chunk = hipops.EncoderParams(), hipops.ChunkParams()
+    null = None
+    assert lib.sur_encoder_forward(null, ctypes.byref(enc), null, 4, null, null) < 0
+    assert b"sur_encoder_forward" in lib.sur_last_error()
+    assert lib.sur_encoder_backward(null, ctypes.byref(enc), null, null, 4, null, 0, 1, null) < 0
+    assert lib.sur_chunk_forward(null, ctypes.byref(chunk), null, null, null, null, null, 0, 1, 1, null, null, null, null, null) < 0
+    assert b"sur_chunk_forward" in lib.sur_last_error()
+    assert lib.sur_chunk_backward(null, ctypes.byref(chunk), null, null, null, null, null, null, null, null, null, null, 1, 1,
+                                  1, null, null, null, null, 0, null) < 0
+    assert lib.sur_flush_encoder_grads(null, ctypes.byref(enc)) < 0      # no partial buffer
+    assert lib.sur_flush_chunk_grads(null, ctypes.byref(chunk)) < 0
+    assert lib.sur_tbptt_delta_loss(null, null, null, 1, 2, 64, 0.25, 0.0, 1.0, null, null, null, null, null, null, null) < 0
+    assert b"sur_tbptt_delta_loss" in lib.sur_last_error()
+    # geometry queries are pure host functions
+    chunk.ca, chunk.cs, chunk.hq, chunk.c_mid = 4, 16, 16, 8
+    sizes = [4 * 16 * 3, 16, 16 * 16 * 3] * 4 + [16 * 16 * 3, 16, 32, 32, 16 * 8 * 3, 8, 64, 64, 8 * 7, 1, 64, 64, 5, 1]
+    for i, n in enumerate(sizes):
+        chunk.size[i] = n
+    assert lib.sur_chunk_saved_floats(ctypes.byref(chunk)) == 3840        # 3 712 floats padded to 1 KiB DMA pieces
+    chunk.hq = 64                                                        # N = 256: the second LDS copy does not fit
+    assert lib.sur_chunk_saved_floats(ctypes.byref(chunk)) == 0
+    enc.n, enc.c[0], enc.c[1], enc.c[2], enc.c[3] = 64, 1, 8, 16, 16
+    enc.stride[0], enc.stride[1], enc.stride[2] = 2, 2, 1
+    assert lib.sur_encoder_saved_floats(ctypes.byref(enc)) == 7 * (8 * 32 + 16 * 16 + 16 * 16)
