@@ -235,6 +235,16 @@ def main():
             traffic = json.load(open(pmc_file)).get(args.workload, {}).get("hbm_bytes_per_launch")
         except (OSError, ValueError):
             traffic = None
+    valu_issue = None
+    try:   # SQ counters of this command (tools/prof_sq.sh): how much of the waves' time the VALU is issuing
+        sq = json.load(open(os.path.join(ROOT, "profiles", "ks_sq_counters.json"))).get(args.workload)
+        if sq:
+            valu_issue = {"frac_of_wave_cycles": sq["fractions_of_wave_cycles"]["SQ_ACTIVE_INST_VALU"],
+                          "wait_frac": sq["fractions_of_wave_cycles"]["SQ_WAIT_ANY"],
+                          "valu_instructions_per_point_substep": sq["valu_instructions_per_point_substep"],
+                          "source": "profiles/ks_sq_counters.json (rocprofv3 --pmc, SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES)"}
+    except (OSError, ValueError, KeyError):
+        valu_issue = None
     total_substeps = n_gpus * E * CFG_STEPS * K
     value = total_substeps / elapsed
     alg_bytes_per_launch = 20.0 * N * E * CFG_STEPS
@@ -272,6 +282,7 @@ def main():
                           "unit": "TFLOP/s",
                           "frac": flops_per_launch / (kernel_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
                           "flops_per_point_substep": FLOPS_PER_POINT_SUBSTEP},
+            "valu_issue": valu_issue,
         },
     }
     if rank == 0 and n_gpus == 1:
