@@ -942,13 +942,18 @@ __host__ __device__ inline int step_saved_floats(const sur_chunk_params& p) {
     return (step_block_floats(p) + DMA_PIECE - 1) / DMA_PIECE * DMA_PIECE;
 }
 
-// staged: the backward kernel keeps TWO copies of the [gates .. a2] block (this step's, and the one the DMA is
+// save_mode of the backward kernel: 0 = recompute the forward; 2 = TWO copies of the [gates .. a2] block (this
+// step's, and the one the DMA is filling for the next step); 1 = one padded copy filled by DMA at the top of the
+// step (when the second copy does not fit in LDS, e.g. N = 256: the load is waited for, still far cheaper than
+// recomputing the step)
+// (mode 2)  staged: the backward kernel keeps TWO copies of the [gates .. a2] block (this step's, and the one the DMA is
 // filling for the next step), each padded to step_saved_floats
-__host__ __device__ inline int step_act_floats(const sur_chunk_params& p, bool backward, bool staged = false) {
+__host__ __device__ inline int step_act_floats(const sur_chunk_params& p, bool backward, int save_mode = 0) {
     const int s = p.cs * p.hq, n = 4 * p.hq;
     int total = p.ca * p.hq + 2 * s + step_block_floats(p) + 2 * n;
     if (backward) total += 4 * s + s + 3 * step_max_act(p) + p.ca * p.hq + s + 2 * s + n;
-    if (staged) total += 2 * step_saved_floats(p) - step_block_floats(p);
+    if (save_mode == 2) total += 2 * step_saved_floats(p) - step_block_floats(p);
+    if (save_mode == 1) total += step_saved_floats(p) - step_block_floats(p);
     return total;
 }
 
@@ -968,7 +973,7 @@ __device__ __forceinline__ void use_block(const sur_chunk_params& p, float* base
     L.a2 = take(n);
 }
 
-__device__ void step_layout(const sur_chunk_params& p, float* lds, bool backward, StepLayout& L, bool staged = false) {
+__device__ void step_layout(const sur_chunk_params& p, float* lds, bool backward, StepLayout& L, int save_mode = 0) {
     const int s = p.cs * p.hq, n = 4 * p.hq;
     float* cur = lds;
     auto take = [&](int k) { float* r = cur; cur += k; return r; };
@@ -976,8 +981,8 @@ __device__ void step_layout(const sur_chunk_params& p, float* lds, bool backward
     L.x = take(p.ca * p.hq);
     L.h = take(s);
     L.c = take(s);
-    L.blk[0] = take(staged ? step_saved_floats(p) : step_block_floats(p));
-    L.blk[1] = staged ? take(step_saved_floats(p)) : nullptr;
+    L.blk[0] = take(save_mode ? step_saved_floats(p) : step_block_floats(p));
+    L.blk[1] = save_mode == 2 ? take(step_saved_floats(p)) : nullptr;
     use_block(p, L.blk[0], L);
     L.d = take(n);
     L.outv = take(n);
@@ -1113,11 +1118,11 @@ chunk_bwd_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, con
                  const float* __restrict__ c_all, const float* __restrict__ dd_all, const float* __restrict__ dout_all,
                  const float* __restrict__ dh_all, const float* __restrict__ dc_all, int K, int S, int B,
                  float* __restrict__ dxlat_t, float* __restrict__ dlstates_t, float* __restrict__ dh0,
-                 float* __restrict__ dc0, int grads_in_lds, int row_base, const float* __restrict__ saved) {
+                 float* __restrict__ dc0, int grads_in_lds, int row_base, const float* __restrict__ saved, int save_mode) {
     extern __shared__ __align__(16) float lds[];
     StepLayout L;
-    const bool staged = saved != nullptr;
-    step_layout(p, lds, true, L, staged);
+    const bool staged = save_mode == 2, direct = save_mode == 1;
+    step_layout(p, lds, true, L, save_mode);
     // Saved forward intermediates: step k-1's block travels HBM -> LDS by LDS-DMA (no registers: this kernel sits
     // at the VGPR cap) into the spare copy blk[1] while step k's cell GEMMs run; the barrier that ends that phase
     // retires the DMA, so its latency is never waited for.  The top of a step moves blk[1] into the working
@@ -1155,6 +1160,7 @@ chunk_bwd_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, con
             L.h[i] = (k < S) ? lstates_t[kb * s + i] : (k > 0 ? h_all[prev] : h0[(size_t)b * s + i]);
             L.c[i] = (k > 0) ? c_all[prev] : c0[(size_t)b * s + i];
         }
+        if (direct) fetch_block(k, L.blk[0]);  // retired by the barrier below
         if (staged) {
             const float4* src = reinterpret_cast<const float4*>(L.blk[1]);
             float4* dst = reinterpret_cast<float4*>(L.blk[0]);
@@ -1162,7 +1168,7 @@ chunk_bwd_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, con
         }
         __syncthreads();
         STAMP(20);
-        if (!staged) step_forward_body(p, L, w);
+        if (!staged && !direct) step_forward_body(p, L, w);
         STAMP(21);
 
         // ---- total gradient wrt d_k: direct + through out_k = base + delta*(d*mul + add) ----
@@ -1435,9 +1441,9 @@ int sur_flush_encoder_grads(void* stream, const sur_encoder_params* p) {
 
 int sur_chunk_saved_floats(const sur_chunk_params* p) {
     if (!p) return 0;
-    // float4 granularity of the block and of its LDS position; the backward kernel's second copy must fit in LDS
+    // float4 granularity of the block and of its LDS position; the padded block must fit in the backward kernel's LDS
     if ((p->hq & 3) || ((p->ca * p->hq) & 3)) return 0;
-    const size_t lds = sizeof(float) * (step_act_floats(*p, true, true) + psize_of<SUR_ST_NPARAM>(p->size));
+    const size_t lds = sizeof(float) * (step_act_floats(*p, true, 1) + psize_of<SUR_ST_NPARAM>(p->size));
     return lds <= LDS_LIMIT ? step_saved_floats(*p) : 0;
 }
 
@@ -1470,14 +1476,16 @@ int sur_chunk_backward(void* stream, const sur_chunk_params* p, const float* xla
     if (!p->partial || row_base < 0 || p->rows < row_base + b)
         return fail(-1, "sur_chunk_backward: partial gradient buffer has %d rows, need [%d, %d)", p->rows, row_base, row_base + b);
     const int psize = psize_of<SUR_ST_NPARAM>(p->size);
-    const size_t base = sizeof(float) * (step_act_floats(*p, true, saved != nullptr) + psize);
+    int save_mode = 0;
+    if (saved) save_mode = sizeof(float) * (step_act_floats(*p, true, 2) + psize) <= LDS_LIMIT ? 2 : 1;
+    const size_t base = sizeof(float) * (step_act_floats(*p, true, save_mode) + psize);
     int grads_in_lds = (base + sizeof(float) * psize <= LDS_LIMIT) ? 1 : 0;
     const size_t lds = base + (grads_in_lds ? sizeof(float) * psize : 0);
     if (int rc = set_lds(chunk_bwd_kernel, lds, "chunk backward")) return rc;
     return launch_checked([&] {
         hipLaunchKernelGGL(chunk_bwd_kernel, dim3(b), dim3(TPB), lds, (hipStream_t)stream, *p, xlat_t, lstates_t, h0, c0, h_all,
                            c_all, dd_all, dout_all, dh_all, dc_all, k, s, b, dxlat_t, dlstates_t, dh0, dc0, grads_in_lds, row_base,
-                           saved);
+                           saved, save_mode);
     }, "chunk_bwd");
 }
 

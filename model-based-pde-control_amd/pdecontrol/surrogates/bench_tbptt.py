@@ -9,13 +9,19 @@ from pdecontrol.surrogates.training import PDETrainingModule
 from pdegym.common.transforms import BatchTransform, Normalize
 
 
-def build_module(device, seed=0):
+def build_module(device, seed=0, N=64):
     torch.manual_seed(seed)
     norm = Normalize(aggregate=True, batched=True)
     norm.mean, norm.var, norm.count = torch.full((1, 1, 1), 0.01), torch.full((1, 1, 1), 0.5), 100
     undscaling = BatchTransform(norm)
-    factory = KSAutoRegConvolutionalLSTM()
-    surrogate = factory.surrogate(delta=0.25, dscaling=undscaling.Inverse, tau=5, **factory.model())
+    if N == 64:
+        factory = KSAutoRegConvolutionalLSTM()
+        model = factory.model()
+    else:   # same architecture resized to N grid points (BASELINE configs[2]: 256)
+        from pdecontrol.architectures import KSAutoRegConvolutionalLSTMN
+        factory = KSAutoRegConvolutionalLSTMN()
+        model = factory.model(N=N)
+    surrogate = factory.surrogate(delta=0.25, dscaling=undscaling.Inverse, tau=5, **model)
     module = PDETrainingModule(surrogate=surrogate, loss=torch.nn.MSELoss(reduction="none"), tstep=0.25, delta=0.25,
                                undscaling=undscaling, tau=5, tbtt=10)
     return module.to(device)
@@ -59,7 +65,7 @@ def first_loss(device, B):
 
 def time_graphed(device, batch, steps, warmup):
     from pdecontrol.surrogates.graph_step import GraphedTBPTTStep
-    graphed = GraphedTBPTTStep(build_module(device), tuple(batch[0].shape))
+    graphed = GraphedTBPTTStep(build_module(device, N=batch[0].shape[-1]), tuple(batch[0].shape))
     graphed.step(*batch)
     for _ in range(warmup):
         graphed.step()
@@ -114,6 +120,13 @@ def run(device, steps=50, warmup=5, B=64, cpu_steps=3):
         ops.enable_fused(True)
         res["hip_graph_fused"] = time_graphed(device, batch, steps * 4, warmup)
         loss_fused = first_loss(device, B)
+        # BASELINE configs[2] names 256 grid points: the same factory resized (N = 256), same B / T / tau / tbtt
+        try:
+            res["n256"] = time_graphed(device, synthetic_batch(B=B, N=256, device=device), steps, warmup)
+            res["n256"]["note"] = ("KSAutoRegConvolutionalLSTMN(N=256); the chunk backward has LDS room for one copy of a step's "
+                                   "intermediates only, so its DMA is waited for at the top of each step")
+        except Exception as exc:
+            res["n256"] = {"error": f"{type(exc).__name__}: {exc}"}
         # the reference's default ensemble (3 members, script.py:60) stepped side by side in one graph
         res["ensemble"] = time_ensemble(device, 3, steps * 2, warmup, B)
     finally:

@@ -81,7 +81,9 @@ def test_surrogate_abi_rejects_bad_arguments_before_touching_the_device():
     for i, n in enumerate(sizes):
         chunk.size[i] = n
     assert lib.sur_chunk_saved_floats(ctypes.byref(chunk)) == 3840        # 3 712 floats padded to 1 KiB DMA pieces
-    chunk.hq = 64                                                        # N = 256: the second LDS copy does not fit
+    chunk.hq = 64                                                        # N = 256: one padded copy still fits
+    assert lib.sur_chunk_saved_floats(ctypes.byref(chunk)) == 14848
+    chunk.hq = 62                                                        # not float4-aligned: no saved path
     assert lib.sur_chunk_saved_floats(ctypes.byref(chunk)) == 0
     enc.n, enc.c[0], enc.c[1], enc.c[2], enc.c[3] = 64, 1, 8, 16, 16
     enc.stride[0], enc.stride[1], enc.stride[2] = 2, 2, 1

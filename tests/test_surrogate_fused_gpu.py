@@ -227,7 +227,7 @@ def test_saved_activations_backward_is_bit_identical_to_recompute(dev, N, monkey
             losses.append(float(out["loss"].detach()))
             if save:
                 f = hipops.load().sur_chunk_saved_floats(__import__("ctypes").byref(m.surrogate._fused_packs.chunk.c))
-                assert (f > 0) == (N == 64), "saved-activation path: expected for N = 64 only (N = 256 has no LDS room)"
+                assert f > 0, "saved-activation path not available for this geometry"
     finally:
         ops.enable_fused(False)
     assert losses[0] == losses[1]
