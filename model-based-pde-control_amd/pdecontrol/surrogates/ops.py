@@ -7,7 +7,6 @@ tensors they use the hand-written gfx950 kernels of libsurrogate_hip.so when ``f
 fusion has been requested).
 """
 import torch
-import torch.nn.functional as F
 
 _FUSED = {"enabled": False, "lib": None}
 

@@ -1,5 +1,4 @@
 """Tiny surrogate forward + backward on cuda:0 for __graft_entry__.smoke()."""
-import numpy as np
 import torch
 
 

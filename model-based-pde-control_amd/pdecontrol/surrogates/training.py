@@ -9,7 +9,6 @@ What is different under the hood: logged values stay tensors (no ``.item()`` hos
 the step), time grids are Python-side, and ``fused_step`` offers the whole
 forward + backward + Adam update as ONE replayable HIP graph for fixed batch shapes.
 """
-from functools import reduce
 from typing import Callable
 
 import numpy as np

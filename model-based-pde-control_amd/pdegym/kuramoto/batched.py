@@ -19,7 +19,6 @@ is kept:
 Multi-GPU: envs are independent, so a job shards them by rank with ``shard_envs`` and every rank
 builds its own KSBatchedVecEnv on its own GPU; no collective is involved.
 """
-import math
 from typing import Optional, Sequence
 
 import numpy as np
