@@ -6,9 +6,13 @@ tensors they use the hand-written gfx950 kernels of libsurrogate_hip.so when ``f
 (``enable_fused(True)`` -- it raises if the library is missing, there is no silent fallback once
 fusion has been requested).
 """
+import os
+
 import torch
 
-_FUSED = {"enabled": False, "lib": None}
+# PDECONTROL_FUSED=1 selects the fused kernels without touching the caller's code (the reference's script.py runs
+# unmodified); the library is loaded at the first CUDA tensor and its absence raises there.
+_FUSED = {"enabled": os.environ.get("PDECONTROL_FUSED", "0") == "1", "lib": None}
 
 
 def enable_fused(flag=True):
@@ -25,7 +29,12 @@ def fused_enabled():
 
 def use_fused(tensor):
     """True when the fused HIP rollout (hipops.fused_rollout) should handle this tensor."""
-    return _FUSED["enabled"] and tensor.is_cuda
+    if not (_FUSED["enabled"] and tensor.is_cuda):
+        return False
+    if _FUSED["lib"] is None:
+        from pdecontrol.surrogates import hipops
+        _FUSED["lib"] = hipops.load()
+    return True
 
 
 def conv_act_norm(x, conv, activation, layernorm):

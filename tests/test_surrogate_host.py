@@ -164,3 +164,18 @@ def test_tbtt_must_exceed_tau():
     s = f.surrogate(delta=0.25, dscaling=None, tau=5, **f.model())
     with pytest.raises(AssertionError):
         PDETrainingModule(surrogate=s, loss=torch.nn.MSELoss(reduction="none"), tstep=0.25, delta=0.25, tau=5, tbtt=5)
+
+
+def test_fused_path_env_switch(monkeypatch):
+    """PDECONTROL_FUSED=1 selects the fused kernels at import; CPU tensors never take that path."""
+    import importlib
+    from pdecontrol.surrogates import ops
+    monkeypatch.setenv("PDECONTROL_FUSED", "1")
+    try:
+        importlib.reload(ops)
+        assert ops.fused_enabled()
+        assert not ops.use_fused(torch.zeros(2))      # CPU tensor: plain torch path, no library load
+    finally:
+        monkeypatch.delenv("PDECONTROL_FUSED")
+        importlib.reload(ops)
+    assert not ops.fused_enabled()
