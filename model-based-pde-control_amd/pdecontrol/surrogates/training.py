@@ -125,6 +125,18 @@ class PDETrainingModule(pl.LightningModule):
                 "actions": actions.detach(), "states": states.detach(), "outdeltas": outdeltas.detach(),
                 "deltas": deltas.detach()}
 
+    def fused_step(self, batch):
+        """One optimizer step -- training_step + backward + Adam(lr) -- as ONE replayed HIP graph on static
+        buffers (pdecontrol.surrogates.graph_step.GraphedTBPTTStep; a graph per batch shape, captured on first
+        use).  Returns training_step's dict; its tensors are overwritten by the next call.  CUDA only."""
+        from pdecontrol.surrogates.graph_step import GraphedTBPTTStep
+        states, actions, *_ = batch
+        key = (tuple(states.shape), tuple(actions.shape))
+        cache = self.__dict__.setdefault("_graphed_steps", {})
+        if key not in cache:
+            cache[key] = GraphedTBPTTStep(self, key[0], key[1])
+        return cache[key].step(states, actions)
+
     # -- validation / test: one un-truncated rollout ------------------------------------------
     def validation_step(self, batch, bidx):
         states, actions, *_ = batch

@@ -78,3 +78,19 @@ def test_hip_graph_step_equals_eager_training():
     pe = torch.cat([p.detach().reshape(-1) for p in eager.surrogate.parameters()])
     pg = torch.cat([p.detach().reshape(-1) for p in graphed.module.surrogate.parameters()])
     assert (pe - pg).abs().max().item() < 5e-4
+
+
+def test_module_fused_step_replays_one_graph_per_shape():
+    """PDETrainingModule.fused_step == GraphedTBPTTStep on the same module state; one graph per batch shape."""
+    from pdecontrol.surrogates.bench_tbptt import build_module, synthetic_batch
+    from pdecontrol.surrogates.graph_step import GraphedTBPTTStep
+    dev = torch.device("cuda", 0)
+    batch = synthetic_batch(B=8, device=dev)
+    ref = GraphedTBPTTStep(build_module(dev), tuple(batch[0].shape))
+    l_ref = [float(ref.step(*batch)["loss"].detach()) for _ in range(3)]
+    m = build_module(dev)
+    l_mod = [float(m.fused_step(batch)["loss"].detach()) for _ in range(3)]
+    assert l_mod == l_ref and l_mod[-1] < l_mod[0]
+    assert len(m._graphed_steps) == 1
+    m.fused_step(synthetic_batch(B=4, device=dev))
+    assert len(m._graphed_steps) == 2
