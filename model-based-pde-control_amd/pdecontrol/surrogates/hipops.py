@@ -232,6 +232,7 @@ class FusedPacks:
         self._flush_queued = False
         self.side_streams = []
         self.loss_scratch = {}
+        self.h0c0 = None
 
     @staticmethod
     def _key(surrogate, n):
@@ -546,8 +547,13 @@ class _TBPTTFn(torch.autograd.Function):
         fork.join()
 
         tm = surrogate.transition_model
-        h0 = tm.H0.unsqueeze(0).expand(b, -1, -1).contiguous()
-        c0 = tm.C0.unsqueeze(0).expand(b, -1, -1).contiguous()
+        # batch-expanded initial hidden / cell state: constant between optimizer steps (H0 / C0 are not trained),
+        # so the two expand kernels run once per (batch size, parameter version), not once per step
+        key = (b, tm.H0.data_ptr(), tm.H0._version, tm.C0.data_ptr(), tm.C0._version)
+        if owner.h0c0 is None or owner.h0c0[0] != key:
+            owner.h0c0 = (key, tm.H0.detach().unsqueeze(0).expand(b, -1, -1).contiguous(),
+                          tm.C0.detach().unsqueeze(0).expand(b, -1, -1).contiguous())
+        _, h0, c0 = owner.h0c0
         seeds, h0s, c0s, h_alls, c_alls, saveds = [states_t0], [h0], [c0], [], [], []
         d_all = torch.empty((t_total, b, 1, n), device=dev, dtype=torch.float32)
         out_all = torch.empty_like(d_all)

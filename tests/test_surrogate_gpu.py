@@ -90,7 +90,9 @@ def test_module_fused_step_replays_one_graph_per_shape():
     l_ref = [float(ref.step(*batch)["loss"].detach()) for _ in range(3)]
     m = build_module(dev)
     l_mod = [float(m.fused_step(batch)["loss"].detach()) for _ in range(3)]
-    assert l_mod == l_ref and l_mod[-1] < l_mod[0]
+    # plain torch / MIOpen kernels under the graph: backward reductions are not bit-reproducible between two captures
+    np.testing.assert_allclose(l_mod, l_ref, rtol=2e-5)
+    assert l_mod[-1] < l_mod[0]
     assert len(m._graphed_steps) == 1
     m.fused_step(synthetic_batch(B=4, device=dev))
     assert len(m._graphed_steps) == 2
