@@ -945,9 +945,7 @@ __host__ __device__ inline int step_saved_floats(const sur_chunk_params& p) {
 // save_mode of the backward kernel: 0 = recompute the forward; 2 = TWO copies of the [gates .. a2] block (this
 // step's, and the one the DMA is filling for the next step); 1 = one padded copy filled by DMA at the top of the
 // step (when the second copy does not fit in LDS, e.g. N = 256: the load is waited for, still far cheaper than
-// recomputing the step)
-// (mode 2)  staged: the backward kernel keeps TWO copies of the [gates .. a2] block (this step's, and the one the DMA is
-// filling for the next step), each padded to step_saved_floats
+// recomputing the step).  Copies are padded to step_saved_floats.
 __host__ __device__ inline int step_act_floats(const sur_chunk_params& p, bool backward, int save_mode = 0) {
     const int s = p.cs * p.hq, n = 4 * p.hq;
     int total = p.ca * p.hq + 2 * s + step_block_floats(p) + 2 * n;
