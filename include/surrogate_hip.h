@@ -11,9 +11,10 @@
  *                                     per step CNNLSTMCell (transition.py:218-226) + state decoder
  *                                     (autoreg.py:79-94) + integration out = base + delta*(d*mul+add);
  *                                     teacher forcing on the first S steps (transition.py:274-279),
- *                                     free running afterwards (:285-296).  The time loop runs INSIDE
- *                                     the kernel: weights stay in LDS, hidden state in LDS, and the
- *                                     backward kernel does the whole BPTT of the chunk in one launch.
+ *                                     free running afterwards (:285-296).  Only the cell is a recurrence: its
+ *                                     time loop runs INSIDE one kernel (weights and hidden state in LDS, one
+ *                                     workgroup per sample); the decoders of all (step, sample) pairs run in
+ *                                     parallel on every CU, forward and backward.
  *   sur_flush_*_grads                 reduces the per-workgroup partial gradient rows into the
  *                                     parameter gradient tensors (deterministic, no atomics)
  *
@@ -82,28 +83,36 @@ int sur_encoder_backward(void* stream, const sur_encoder_params* p, const float*
                          float* dx, int row_base, int row_count, const float* saved /* or NULL = recompute */);
 int sur_flush_encoder_grads(void* stream, const sur_encoder_params* p);
 
-/* Floats per (step, sample) of the forward intermediates sur_chunk_forward can save for sur_chunk_backward
- * (activated gates, c_k, h_k, decoder activations), or 0 if this geometry has no saved-activation path.
- * With a `saved` buffer [K,B,sur_chunk_saved_floats] the backward kernel streams the intermediates back from
- * HBM (prefetched one step ahead) instead of recomputing the step's forward: 12.8 KB per step and sample at
- * N = 64 -- HBM capacity and bandwidth are free on this device, dependent-phase latency is not. */
+/* Floats per (step, sample) of the forward intermediates sur_chunk_forward saves for sur_chunk_backward (activated
+ * gates, c_k, h_k, decoder pre-/post-LayerNorm activations; 14.8 KB at N = 64), or 0 if the latent sizes are not
+ * float4-granular (then only the forward is available).  The backward kernels read the intermediates back from HBM
+ * instead of recomputing the steps -- HBM capacity and bandwidth are free on this device, dependent-phase latency
+ * is not. */
 int sur_chunk_saved_floats(const sur_chunk_params* p);
 
-/* Time-major tensors: xlat_t [K,B,ca,hq]; lstates_t [S,B,cs,hq] (encoded given states, S >= 1);
+/* Floats of the scratch buffer sur_chunk_backward needs for its split path (0: bad arguments). */
+int sur_chunk_workspace_floats(const sur_chunk_params* p, int k, int b);
+
+/* Only the ConvLSTM cell is a recurrence: sur_chunk_forward runs the cell chain with one workgroup per sample, then
+ * the decoders of ALL (step, sample) pairs in parallel on every CU, then the integration; sur_chunk_backward (given
+ * `saved` and `workspace`) runs the decoder backward of all pairs in parallel, then the cell chain's BPTT.
+ *
+ * Time-major tensors: xlat_t [K,B,ca,hq]; lstates_t [S,B,cs,hq] (encoded given states, S >= 1);
  * states_t [S,B,1,N] (the given states: bases of the teacher-forced steps); h0, c0 [B,cs,hq].
  * Outputs: h_all, c_all [K,B,cs,hq]; d_all, out_all [K,B,1,N]. */
 int sur_chunk_forward(void* stream, const sur_chunk_params* p, const float* xlat_t, const float* lstates_t,
                       const float* states_t, const float* h0, const float* c0, int k, int s, int b, float* h_all,
-                      float* c_all, float* d_all, float* out_all, float* saved /* may be NULL */);
+                      float* c_all, float* d_all, float* out_all, float* saved /* NULL: forward only, no backward later */);
 /* Upstream gradients (each may be NULL = 0): dd_all / dout_all [K,B,1,N] wrt d_all / out_all;
  * dh_all / dc_all [K,B,cs,hq] wrt h_all / c_all.  Outputs (each may be NULL): dxlat_t [K,B,ca,hq],
  * dlstates_t [S,B,cs,hq], dh0, dc0 [B,cs,hq].  Accumulates parameter gradients into rows
- * [row_base, row_base + B) of p->partial.  Results are bit-identical with and without `saved`. */
+ * [row_base, row_base + row_count) of p->partial (row_count >= B; the parallel decoder backward uses one row
+ * per workgroup, up to row_count of them). */
 int sur_chunk_backward(void* stream, const sur_chunk_params* p, const float* xlat_t, const float* lstates_t,
                        const float* h0, const float* c0, const float* h_all, const float* c_all,
                        const float* dd_all, const float* dout_all, const float* dh_all, const float* dc_all, int k,
-                       int s, int b, float* dxlat_t, float* dlstates_t, float* dh0, float* dc0, int row_base,
-                       const float* saved /* what sur_chunk_forward wrote, or NULL = recompute */);
+                       int s, int b, float* dxlat_t, float* dlstates_t, float* dh0, float* dc0, int row_base, int row_count,
+                       const float* saved /* what sur_chunk_forward wrote */, float* workspace /* sur_chunk_workspace_floats */);
 int sur_flush_chunk_grads(void* stream, const sur_chunk_params* p);
 
 /* Delta-mode TBPTT loss in one launch (reference: pdecontrol/surrogates/training.py:100-121):

@@ -918,7 +918,6 @@ delta_loss_kernel(const float* __restrict__ states, const float* __restrict__ d_
 // ---------------------------------------------------------------------------------------------
 struct StepLayout {
     float *x, *h, *c, *gates, *cnew, *hnew, *p0, *a0, *p1, *a1, *p2, *a2, *d, *outv;
-    float* blk[2];  // staged backward: the two copies of the [gates .. a2] block
     // backward only
     float *dgates, *dh, *gA, *gB, *xh, *dx, *dhin, *dh_carry, *dc_carry, *dout_carry;
     float* end;
@@ -942,66 +941,8 @@ __host__ __device__ inline int step_saved_floats(const sur_chunk_params& p) {
     return (step_block_floats(p) + DMA_PIECE - 1) / DMA_PIECE * DMA_PIECE;
 }
 
-// save_mode of the backward kernel: 0 = recompute the forward; 2 = TWO copies of the [gates .. a2] block (this
-// step's, and the one the DMA is filling for the next step); 1 = one padded copy filled by DMA at the top of the
-// step (when the second copy does not fit in LDS, e.g. N = 256: the load is waited for, still far cheaper than
-// recomputing the step).  Copies are padded to step_saved_floats.
-__host__ __device__ inline int step_act_floats(const sur_chunk_params& p, bool backward, int save_mode = 0) {
-    const int s = p.cs * p.hq, n = 4 * p.hq;
-    int total = p.ca * p.hq + 2 * s + step_block_floats(p) + 2 * n;
-    if (backward) total += 4 * s + s + 3 * step_max_act(p) + p.ca * p.hq + s + 2 * s + n;
-    if (save_mode == 2) total += 2 * step_saved_floats(p) - step_block_floats(p);
-    if (save_mode == 1) total += step_saved_floats(p) - step_block_floats(p);
-    return total;
-}
-
-// point the forward-intermediate views at a [gates .. a2] block
-__device__ __forceinline__ void use_block(const sur_chunk_params& p, float* base, StepLayout& L) {
-    const int s = p.cs * p.hq, n = 4 * p.hq;
-    float* cur = base;
-    auto take = [&](int k) { float* r = cur; cur += k; return r; };
-    L.gates = take(4 * s);
-    L.cnew = take(s);
-    L.hnew = take(s);
-    L.p0 = take(p.cs * 2 * p.hq);
-    L.a0 = take(p.cs * 2 * p.hq);
-    L.p1 = take(p.c_mid * n);
-    L.a1 = take(p.c_mid * n);
-    L.p2 = take(n);
-    L.a2 = take(n);
-}
-
-__device__ void step_layout(const sur_chunk_params& p, float* lds, bool backward, StepLayout& L, int save_mode = 0) {
-    const int s = p.cs * p.hq, n = 4 * p.hq;
-    float* cur = lds;
-    auto take = [&](int k) { float* r = cur; cur += k; return r; };
-    L.n = n;
-    L.x = take(p.ca * p.hq);
-    L.h = take(s);
-    L.c = take(s);
-    L.blk[0] = take(save_mode ? step_saved_floats(p) : step_block_floats(p));
-    L.blk[1] = save_mode == 2 ? take(step_saved_floats(p)) : nullptr;
-    use_block(p, L.blk[0], L);
-    L.d = take(n);
-    L.outv = take(n);
-    if (backward) {
-        const int m = step_max_act(p);
-        L.dgates = take(4 * s);
-        L.dh = take(s);
-        L.gA = take(m);
-        L.gB = take(m);
-        L.xh = take(m);
-        L.dx = take(p.ca * p.hq);
-        L.dhin = take(s);
-        L.dh_carry = take(s);
-        L.dc_carry = take(s);
-        L.dout_carry = take(n);
-    }
-    L.end = cur;
-}
-
-// one rollout step on LDS-resident x, h, c: fills gates (activated), cnew, hnew, decoder activations, d
-__device__ void step_forward_body(const sur_chunk_params& p, const StepLayout& L, const float* const* w) {
+// ConvLSTM cell on LDS-resident x, h, c: fills gates (activated), cnew, hnew
+__device__ void cell_forward(const sur_chunk_params& p, const StepLayout& L, const float* const* w) {
     const int s = p.cs * p.hq;
     STAMP(0);
     // all four gates' pre-activations in ONE gather-GEMM: rows = (gate, channel), K = 3*(ca + cs).
@@ -1042,6 +983,10 @@ __device__ void step_forward_body(const sur_chunk_params& p, const StepLayout& L
     }
     __syncthreads();
     STAMP(2);
+}
+
+// state decoder on LDS-resident hnew: fills p0, a0, p1, a1, p2, a2 and d
+__device__ void decoder_forward(const sur_chunk_params& p, const StepLayout& L, const float* const* w) {
     deconv_fwd(L.hnew, p.cs, p.hq, w[SUR_ST_DC0_W], w[SUR_ST_DC0_B], p.cs, L.p0);
     STAMP(3);
     act_ln_fwd(L.p0, p.cs, 2 * p.hq, w[SUR_ST_LN0_W], w[SUR_ST_LN0_B], true, L.a0);
@@ -1058,153 +1003,394 @@ __device__ void step_forward_body(const sur_chunk_params& p, const StepLayout& L
     STAMP(9);
 }
 
+// decoder backward on LDS-resident activations: L.gA holds d loss / d d on entry, L.dh the gradient wrt hnew on exit
+__device__ void decoder_backward(const sur_chunk_params& p, const StepLayout& L, const float* const* w, float* const* g) {
+    const int n = L.n;
+    conv_bwd_weight<5>(L.gA, 1, L.a2, 1, n, 1, 2, g[SUR_ST_CV3_W], g[SUR_ST_CV3_B], all_waves(), false);
+    STAMP(12);
+    conv_bwd_data<5>(L.gA, 1, n, w[SUR_ST_CV3_W], 1, 1, 2, L.gB, false);
+    STAMP(13);
+    act_ln_bwd(L.gB, L.p2, 1, n, w[SUR_ST_LN2_W], true, L.gA, L.xh, g[SUR_ST_LN2_W], g[SUR_ST_LN2_B]);
+    STAMP(14);
+    conv_bwd_weight<7>(L.gA, 1, L.a1, p.c_mid, n, 1, 3, g[SUR_ST_CV2_W], g[SUR_ST_CV2_B], all_waves(), false);
+    STAMP(15);
+    conv_bwd_data<7>(L.gA, 1, n, w[SUR_ST_CV2_W], p.c_mid, 1, 3, L.gB, false);
+    STAMP(16);
+    act_ln_bwd(L.gB, L.p1, p.c_mid, n, w[SUR_ST_LN1_W], true, L.gA, L.xh, g[SUR_ST_LN1_W], g[SUR_ST_LN1_B]);
+    STAMP(17);
+    deconv_bwd_weight(L.gA, p.c_mid, L.a0, p.cs, 2 * p.hq, g[SUR_ST_DC1_W], g[SUR_ST_DC1_B], lower_half(), false);
+    STAMP(18);
+    deconv_bwd_data(L.gA, p.c_mid, 2 * p.hq, w[SUR_ST_DC1_W], p.cs, L.gB, upper_half(), true);
+    STAMP(19);
+    act_ln_bwd(L.gB, L.p0, p.cs, 2 * p.hq, w[SUR_ST_LN0_W], true, L.gA, L.xh, g[SUR_ST_LN0_W], g[SUR_ST_LN0_B]);
+    STAMP(26);
+    deconv_bwd_weight(L.gA, p.cs, L.hnew, p.cs, p.hq, g[SUR_ST_DC0_W], g[SUR_ST_DC0_B], lower_half(), false);
+    STAMP(27);
+    deconv_bwd_data(L.gA, p.cs, p.hq, w[SUR_ST_DC0_W], p.cs, L.dh, upper_half(), true);
+
+}
+
+// cell backward GEMMs on LDS-resident gate gradients L.dgates: L.dx, L.dhin and the LSTM weight / bias gradients
+__device__ void cell_backward_gemms(const sur_chunk_params& p, const StepLayout& L, const float* const* w, float* const* g) {
+    const int s = p.cs * p.hq;
+    {
+        // four independent GEMMs on the gate gradients dG [4*cs][hq], issued without barriers in between:
+        //   dx  [ca][hq]  = sum_g Wx_g^T * dG_g     (waves: first quarter)
+        //   dh  [cs][hq]  = sum_g Wh_g^T * dG_g     (second quarter)
+        //   gWx, gWh, gb  = dG_g x {x, h}           (second half)
+        const int nwg = blockDim.x >> 6, cs = p.cs, ca = p.ca, hq = p.hq;
+        const int gate_stride = (int)(w[SUR_ST_WXF] - w[SUR_ST_WXI]);
+        const WaveSet w_dx = nwg >= 4 ? WaveSet{0, nwg / 4} : all_waves();
+        const WaveSet w_dh = nwg >= 4 ? WaveSet{nwg / 4, nwg / 4} : all_waves();
+        const WaveSet w_gw = nwg >= 4 ? WaveSet{nwg / 2, nwg - nwg / 2} : all_waves();
+        auto tap_col = [&](int, int tap, int j) { return wrapi(j - tap + 1, hq); };  // stride 1, pad 1
+        {   // A[m=ci][c=o][tap] = W_g[(o*cin + ci)*3 + tap];  B = dG_g[o][col]
+            const float* wx = w[SUR_ST_WXI];
+            const GemmSeg sx[4] = {{wx, 3, ca * 3, L.dgates, hq, cs},
+                                   {wx + gate_stride, 3, ca * 3, L.dgates + s, hq, cs},
+                                   {wx + 2 * gate_stride, 3, ca * 3, L.dgates + 2 * s, hq, cs},
+                                   {wx + 3 * gate_stride, 3, ca * 3, L.dgates + 3 * s, hq, cs}};
+            float* dxp = L.dx;
+            gemm_taps<3, 4>(w_dx, false, ca, hq, sx, tap_col, [&](int m, int j, float v) {
+                if (m < ca) dxp[m * hq + j] = v;
+            });
+            STAMP(28);
+            const float* wh = w[SUR_ST_WHI];
+            const GemmSeg sh[4] = {{wh, 3, cs * 3, L.dgates, hq, cs},
+                                   {wh + gate_stride, 3, cs * 3, L.dgates + s, hq, cs},
+                                   {wh + 2 * gate_stride, 3, cs * 3, L.dgates + 2 * s, hq, cs},
+                                   {wh + 3 * gate_stride, 3, cs * 3, L.dgates + 3 * s, hq, cs}};
+            float* dhp = L.dhin;
+            gemm_taps<3, 4>(w_dh, false, cs, hq, sh, tap_col, [&](int m, int j, float v) {
+                if (m < cs) dhp[m * hq + j] = v;
+            });
+            STAMP(29);
+        }
+        // weight gradients, all gates in one GEMM each: rows m = (gate, o)
+        struct St { const float* row; int off; };
+        {
+            float* gx = g[SUR_ST_WXI];
+            const float* xin = L.x;
+            const int ncols = ca * 3;
+            gemm_pos(w_gw, false, 4 * cs, ncols, hq, L.dgates, hq,
+                     [&](int n) { const int ci = n / 3, k = n - ci * 3; return St{xin + ci * hq, k - 1}; },
+                     [&](const St& st, int pp) { return st.row[wrapi(pp + st.off, hq)]; },
+                     [&](int m, int n, float v) {
+                         if (m < 4 * cs && n < ncols) {
+                             const int gt = m / cs, o = m - gt * cs;
+                             gx[gt * gate_stride + o * ncols + n] += v;
+                         }
+                     });
+            STAMP(30);
+            float* gh = g[SUR_ST_WHI];
+            const float* hin_ = L.h;
+            const int ncols_h = cs * 3;
+            // the dx / dh waves finish well before the two weight-gradient waves: they take the last third of
+            // the gWh tiles (measured alone: dx 10.6 k, dh 9.1 k, gWx + gWh 18.7 k cycles on two waves)
+            const int th_all = ((4 * cs + 15) >> 4) * ((ncols_h + 15) >> 4), th_split = nwg >= 4 ? (2 * th_all) / 3 : th_all;
+            auto gwh = [&](WaveSet wset, int lo, int hi) {
+                gemm_pos(wset, false, 4 * cs, ncols_h, hq, L.dgates, hq,
+                         [&](int n) { const int ci = n / 3, k = n - ci * 3; return St{hin_ + ci * hq, k - 1}; },
+                         [&](const St& st, int pp) { return st.row[wrapi(pp + st.off, hq)]; },
+                         [&](int m, int n, float v) {
+                             if (m < 4 * cs && n < ncols_h) {
+                                 const int gt = m / cs, o = m - gt * cs;
+                                 gh[gt * gate_stride + o * ncols_h + n] += v;
+                             }
+                         }, lo, hi);
+            };
+            gwh(w_gw, 0, th_split);
+            if (th_split < th_all) gwh(WaveSet{0, nwg / 2}, th_split, th_all);
+            STAMP(31);
+            float* gbx = g[SUR_ST_BXI];
+            for (int idx = threadIdx.x; idx < 4 * cs; idx += blockDim.x) {
+                const int gt = idx / cs, o = idx - gt * cs;
+                float a0 = 0.0f, a1 = 0.0f;
+                for (int pp = 0; pp < hq; pp += 2) {
+                    a0 += L.dgates[idx * hq + pp];
+                    a1 += L.dgates[idx * hq + pp + 1];
+                }
+                gbx[gt * gate_stride + o] += a0 + a1;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Split path: only the ConvLSTM cell is a recurrence.  The decoder of step k reads h_k and feeds nothing back
+// into step k+1 (the reference's transition ignores the re-encoded prediction, transition.py:285-296; teacher
+// forcing replaces H by the encoded true state), so it is evaluated for ALL (step, sample) pairs in parallel,
+// forward and backward, by persistent workgroups on every CU, while the chain kernels (one workgroup per
+// sample) carry only the cell.  Layout of a saved block (step_saved_floats per (step, sample)):
+//   [ gates 4s | c_k s | h_k s | p0 | a0 | p1 | a1 | p2 | a2 ]     cell part = first 6s floats
+// ---------------------------------------------------------------------------------------------
+constexpr int ST_NLSTM = SUR_ST_DC0_W;              // the LSTM parameters come first in the chunk parameter order
+constexpr int ST_NDEC = SUR_ST_NPARAM - ST_NLSTM;
+
+__host__ __device__ inline int cell_part_floats(const sur_chunk_params& p) { return 6 * p.cs * p.hq; }
+__host__ __device__ inline int dec_part_floats(const sur_chunk_params& p) { return step_block_floats(p) - cell_part_floats(p); }
+__host__ __device__ inline int cell_fwd_act_floats(const sur_chunk_params& p) { return p.ca * p.hq + 8 * p.cs * p.hq; }
+__host__ __device__ inline int cell_bwd_act_floats(const sur_chunk_params& p) {
+    const int s = p.cs * p.hq;   // x, h, c, [gates|cnew] twice (working copy + DMA target), dgates, dx, dhin, two carries
+    return p.ca * p.hq + 2 * s + 2 * 5 * s + 4 * s + p.ca * p.hq + s + 2 * s;
+}
+__host__ __device__ inline int dec_act_floats(const sur_chunk_params& p, bool backward) {
+    const int s = p.cs * p.hq, n = 4 * p.hq;
+    int total = s + dec_part_floats(p) + n;             // hnew, p0..a2, d
+    if (backward) total += 3 * step_max_act(p) + s;      // gA, gB, xh, dh
+    return total;
+}
+
+template <int NP>
+__device__ __forceinline__ void stage_range(const sur_chunk_params& p, int first, float* lds_w, const float** w) {
+    ParamViews<NP> v;
+    stage_weights<NP>(p.w + first, p.size + first, lds_w, v);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) w[first + i] = v.w[i];
+}
+
 __global__ void __launch_bounds__(TPB)
-chunk_fwd_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, const float* __restrict__ lstates_t,
-                 const float* __restrict__ states_t, const float* __restrict__ h0, const float* __restrict__ c0, int K,
-                 int S, int B, float* __restrict__ h_all, float* __restrict__ c_all, float* __restrict__ d_all,
-                 float* __restrict__ out_all, float* __restrict__ saved) {
+cell_fwd_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, const float* __restrict__ lstates_t,
+                const float* __restrict__ h0, const float* __restrict__ c0, int K, int S, int B, float* __restrict__ h_all,
+                float* __restrict__ c_all, float* __restrict__ saved) {
     extern __shared__ __align__(16) float lds[];
-    StepLayout L;
-    step_layout(p, lds, false, L);
-    const int nsave4 = step_block_floats(p) >> 2;
+    const int b = blockIdx.x, s = p.cs * p.hq, nx = p.ca * p.hq;
+    StepLayout L{};
+    L.x = lds;
+    L.h = L.x + nx;
+    L.c = L.h + s;
+    L.gates = L.c + s;
+    L.cnew = L.gates + 4 * s;
+    L.hnew = L.cnew + s;
+    const float* w[SUR_ST_NPARAM];
+    stage_range<ST_NLSTM>(p, 0, L.hnew + s, w);
     const size_t save_stride = step_saved_floats(p);
-    ParamViews<SUR_ST_NPARAM> v;
-    stage_weights<SUR_ST_NPARAM>(p.w, p.size, L.end, v);
-    const int b = blockIdx.x, s = p.cs * p.hq, nx = p.ca * p.hq, n = L.n;
     for (int i = threadIdx.x; i < s; i += blockDim.x) {
-        L.hnew[i] = h0[(size_t)b * s + i];  // "previous" hidden state
+        L.hnew[i] = h0[(size_t)b * s + i];
         L.cnew[i] = c0[(size_t)b * s + i];
     }
+    // the next step's latent action is fetched while this step computes
+    float xn[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) xn[u] = threadIdx.x + u * TPB < nx ? xlat_t[(size_t)b * nx + threadIdx.x + u * TPB] : 0.0f;
     __syncthreads();
     for (int k = 0; k < K; ++k) {
         const size_t kb = (size_t)k * B + b;
-        for (int i = threadIdx.x; i < nx; i += blockDim.x) L.x[i] = xlat_t[kb * nx + i];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (threadIdx.x + u * TPB < nx) L.x[threadIdx.x + u * TPB] = xn[u];
+        for (int i = threadIdx.x + 4 * TPB; i < nx; i += blockDim.x) L.x[i] = xlat_t[kb * nx + i];
         for (int i = threadIdx.x; i < s; i += blockDim.x) {
             L.h[i] = (k < S) ? lstates_t[kb * s + i] : L.hnew[i];  // teacher forcing replaces H
             L.c[i] = L.cnew[i];
         }
-        // base of the integration: the given state while teacher forcing, else the previous output
-        if (k < S)
-            for (int i = threadIdx.x; i < n; i += blockDim.x) L.outv[i] = states_t[kb * n + i];
         __syncthreads();
-        STAMP(10);
-        step_forward_body(p, L, v.w);
-        if (saved) {  // every intermediate the backward kernel needs: it then skips the recomputation
-            float4* dst = reinterpret_cast<float4*>(saved + kb * save_stride);
-            const float4* src = reinterpret_cast<const float4*>(L.gates);
-            for (int i = threadIdx.x; i < nsave4; i += blockDim.x) dst[i] = src[i];
+        if (k + 1 < K) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (threadIdx.x + u * TPB < nx) xn[u] = xlat_t[(kb + B) * nx + threadIdx.x + u * TPB];
         }
+        cell_forward(p, L, w);
         for (int i = threadIdx.x; i < s; i += blockDim.x) {
             h_all[kb * s + i] = L.hnew[i];
             c_all[kb * s + i] = L.cnew[i];
         }
-        for (int i = threadIdx.x; i < n; i += blockDim.x) {
-            const float d = L.d[i];
-            const float o = L.outv[i] + p.delta * fmaf(d, p.mul, p.add);
-            d_all[kb * n + i] = d;
-            out_all[kb * n + i] = o;
-            L.outv[i] = o;
+        if (saved) {   // [gates | c_k | h_k]
+            float4* dst = reinterpret_cast<float4*>(saved + kb * save_stride);
+            const float4* src = reinterpret_cast<const float4*>(L.gates);
+            for (int i = threadIdx.x; i < (6 * s) >> 2; i += blockDim.x) dst[i] = src[i];
         }
         __syncthreads();
-        STAMP(11);
     }
 }
 
-__global__ void __launch_bounds__(TPB)
-chunk_bwd_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, const float* __restrict__ lstates_t,
-                 const float* __restrict__ h0, const float* __restrict__ c0, const float* __restrict__ h_all,
-                 const float* __restrict__ c_all, const float* __restrict__ dd_all, const float* __restrict__ dout_all,
-                 const float* __restrict__ dh_all, const float* __restrict__ dc_all, int K, int S, int B,
-                 float* __restrict__ dxlat_t, float* __restrict__ dlstates_t, float* __restrict__ dh0,
-                 float* __restrict__ dc0, int grads_in_lds, int row_base, const float* __restrict__ saved, int save_mode) {
+// decoder of every (step, sample) pair m: d_all[m] from h_all[m]; persistent workgroups
+__global__ void __launch_bounds__(TPB, 2)
+dec_fwd_kernel(const sur_chunk_params p, const float* __restrict__ h_all, int M, float* __restrict__ d_all,
+               float* __restrict__ saved) {
     extern __shared__ __align__(16) float lds[];
-    StepLayout L;
-    const bool staged = save_mode == 2, direct = save_mode == 1;
-    step_layout(p, lds, true, L, save_mode);
-    // Saved forward intermediates: step k-1's block travels HBM -> LDS by LDS-DMA (no registers: this kernel sits
-    // at the VGPR cap) into the spare copy blk[1] while step k's cell GEMMs run; the barrier that ends that phase
-    // retires the DMA, so its latency is never waited for.  The top of a step moves blk[1] into the working
-    // copy blk[0] (LDS -> LDS, a few hundred cycles) so every view keeps its fixed address.
-    const int npieces = step_saved_floats(p) / DMA_PIECE;
-    auto fetch_block = [&](int kk, float* dst) {
-        const float* src = saved + ((size_t)kk * B + blockIdx.x) * (size_t)(npieces * DMA_PIECE);
+    const int s = p.cs * p.hq, n = 4 * p.hq;
+    StepLayout L{};
+    L.n = n;
+    L.hnew = lds;
+    L.p0 = L.hnew + s;
+    L.a0 = L.p0 + p.cs * 2 * p.hq;
+    L.p1 = L.a0 + p.cs * 2 * p.hq;
+    L.a1 = L.p1 + p.c_mid * n;
+    L.p2 = L.a1 + p.c_mid * n;
+    L.a2 = L.p2 + n;
+    L.d = L.a2 + n;
+    const float* w[SUR_ST_NPARAM];
+    stage_range<ST_NDEC>(p, ST_NLSTM, L.d + n, w);
+    const size_t save_stride = step_saved_floats(p);
+    const int ndec4 = dec_part_floats(p) >> 2;
+    for (int m = blockIdx.x; m < M; m += gridDim.x) {
+        lds_load_v4(L.hnew, h_all + (size_t)m * s, s >> 2);
+        decoder_forward(p, L, w);
+        for (int i = threadIdx.x; i < n; i += blockDim.x) d_all[(size_t)m * n + i] = L.d[i];
+        if (saved) {
+            float4* dst = reinterpret_cast<float4*>(saved + (size_t)m * save_stride + 6 * s);
+            const float4* src = reinterpret_cast<const float4*>(L.p0);
+            for (int i = threadIdx.x; i < ndec4; i += blockDim.x) dst[i] = src[i];
+        }
+        __syncthreads();
+    }
+}
+
+// out_k = base_k + delta * (d_k * mul + add); base_k = the given state while teacher forcing, else out_{k-1}
+__global__ void __launch_bounds__(TPB)
+integrate_kernel(const float* __restrict__ states_t, const float* __restrict__ d_all, int K, int S, int B, int n, float delta,
+                 float mul, float add, float* __restrict__ out_all) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= B * n) return;
+    float prev = 0.0f;
+    for (int k = 0; k < K; ++k) {
+        const size_t idx = (size_t)k * B * n + e;
+        const float base = k < S ? states_t[idx] : prev;
+        prev = base + delta * fmaf(d_all[idx], mul, add);
+        out_all[idx] = prev;
+    }
+}
+
+// total gradient wrt d_k: direct + through out_k (and through the outputs after it while free running)
+__global__ void __launch_bounds__(TPB)
+dgrad_scan_kernel(const float* __restrict__ dd_all, const float* __restrict__ dout_all, int K, int S, int B, int n, float scale,
+                  float* __restrict__ ga_all) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= B * n) return;
+    float carry = 0.0f;
+    for (int k = K - 1; k >= 0; --k) {
+        const size_t idx = (size_t)k * B * n + e;
+        const float go = (dout_all ? dout_all[idx] : 0.0f) + carry;
+        ga_all[idx] = fmaf(scale, go, dd_all ? dd_all[idx] : 0.0f);
+        carry = (k >= S) ? go : 0.0f;   // out_{k-1} is the base of step k only while free running
+    }
+}
+
+// decoder backward of every (step, sample) pair: dh_dec[m] = d loss / d h_m through the decoder; decoder parameter
+// gradients into this workgroup's partial row.  Built for two workgroups per CU.
+__global__ void __launch_bounds__(TPB, 2)
+dec_bwd_kernel(const sur_chunk_params p, const float* __restrict__ saved, const float* __restrict__ ga_all, int M,
+               float* __restrict__ dh_dec, int grads_in_lds, int row_base) {
+    extern __shared__ __align__(16) float lds[];
+    const int s = p.cs * p.hq, n = 4 * p.hq, mx = step_max_act(p);
+    StepLayout L{};
+    L.n = n;
+    L.hnew = lds;
+    L.p0 = L.hnew + s;
+    L.a0 = L.p0 + p.cs * 2 * p.hq;
+    L.p1 = L.a0 + p.cs * 2 * p.hq;
+    L.a1 = L.p1 + p.c_mid * n;
+    L.p2 = L.a1 + p.c_mid * n;
+    L.a2 = L.p2 + n;
+    L.d = L.a2 + n;
+    L.gA = L.d + n;
+    L.gB = L.gA + mx;
+    L.xh = L.gB + mx;
+    L.dh = L.xh + mx;
+    float* wbase = L.dh + s;
+    const float* w[SUR_ST_NPARAM];
+    stage_range<ST_NDEC>(p, ST_NLSTM, wbase, w);
+    int off_dec = 0, psize_dec = 0;
+    for (int i = 0; i < ST_NLSTM; ++i) off_dec += p.size[i];
+    for (int i = ST_NLSTM; i < SUR_ST_NPARAM; ++i) psize_dec += p.size[i];
+    const int psize = off_dec + psize_dec;
+    float* row = p.partial + (size_t)(row_base + blockIdx.x) * psize + off_dec;
+    float* gacc = grads_in_lds ? wbase + psize_dec : row;
+    float* g[SUR_ST_NPARAM];
+    {
+        int off = 0;
+        for (int i = ST_NLSTM; i < SUR_ST_NPARAM; ++i) {
+            g[i] = gacc + off;
+            off += p.size[i];
+        }
+        if (grads_in_lds)
+            for (int j = threadIdx.x; j < psize_dec; j += blockDim.x) gacc[j] = 0.0f;
+    }
+    __syncthreads();
+    const size_t save_stride = step_saved_floats(p);
+    const int nload4 = (s + dec_part_floats(p)) >> 2;   // [h_k | p0 .. a2] is contiguous in the saved block
+    for (int m = blockIdx.x; m < M; m += gridDim.x) {
+        for (int i = threadIdx.x; i < n; i += blockDim.x) L.gA[i] = ga_all[(size_t)m * n + i];
+        lds_load_v4(L.hnew, saved + (size_t)m * save_stride + 5 * s, nload4);
+        decoder_backward(p, L, w, g);
+        for (int i = threadIdx.x; i < s; i += blockDim.x) dh_dec[(size_t)m * s + i] = L.dh[i];
+        __syncthreads();
+    }
+    if (grads_in_lds) add_to_row(row, gacc, psize_dec);
+}
+
+// BPTT through the cell chain of one sample: consumes dh_dec (decoder) and the upstream dh / dc gradients
+__global__ void __launch_bounds__(TPB)
+cell_bwd_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, const float* __restrict__ lstates_t,
+                const float* __restrict__ h0, const float* __restrict__ c0, const float* __restrict__ h_all,
+                const float* __restrict__ c_all, const float* __restrict__ saved, const float* __restrict__ dh_dec,
+                const float* __restrict__ dh_all, const float* __restrict__ dc_all, int K, int S, int B,
+                float* __restrict__ dxlat_t, float* __restrict__ dlstates_t, float* __restrict__ dh0, float* __restrict__ dc0,
+                int grads_in_lds, int row_base) {
+    extern __shared__ __align__(16) float lds[];
+    const int b = blockIdx.x, s = p.cs * p.hq, nx = p.ca * p.hq;
+    StepLayout L{};
+    L.x = lds;
+    L.h = L.x + nx;
+    L.c = L.h + s;
+    L.gates = L.c + s;          // working copy of [gates | c_k]
+    L.cnew = L.gates + 4 * s;
+    float* next_blk = L.cnew + s;   // DMA target for the next step's [gates | c_k]
+    L.dgates = next_blk + 5 * s;
+    L.dx = L.dgates + 4 * s;
+    L.dhin = L.dx + nx;
+    L.dh_carry = L.dhin + s;
+    L.dc_carry = L.dh_carry + s;
+    float* wbase = L.dc_carry + s;
+    const size_t save_stride = step_saved_floats(p);
+    const int npieces = (5 * s) / DMA_PIECE;   // a whole number: checked on the host
+    auto fetch_block = [&](int kk) {
+        const float* src = saved + ((size_t)kk * B + b) * save_stride;
         const int lane = threadIdx.x & 63;
         for (int j = threadIdx.x >> 6; j < npieces; j += blockDim.x >> 6)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + j * DMA_PIECE + lane * 4),
-                                             (__attribute__((address_space(3))) void*)(dst + j * DMA_PIECE + lane * 4), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(next_blk + j * DMA_PIECE + lane * 4), 16, 0, 0);
     };
-    if (staged) fetch_block(K - 1, L.blk[1]);
-    const int nblock4 = step_block_floats(p) >> 2;
-    ParamViews<SUR_ST_NPARAM> v;
-    stage_weights<SUR_ST_NPARAM>(p.w, p.size, L.end, v);
-    const int psize = psize_of<SUR_ST_NPARAM>(p.size);
-    float* row = p.partial + (size_t)(row_base + blockIdx.x) * psize;
-    float* gacc = grads_in_lds ? L.end + psize : row;
-    setup_grads<SUR_ST_NPARAM>(p.size, gacc, grads_in_lds != 0, v);
-    const float* const* w = v.w;
-    float* const* g = v.g;
-
-    const int b = blockIdx.x, s = p.cs * p.hq, nx = p.ca * p.hq, n = L.n;
+    fetch_block(K - 1);
+    const float* w[SUR_ST_NPARAM];
+    stage_range<ST_NLSTM>(p, 0, wbase, w);
+    int psize_lstm = 0;
+    for (int i = 0; i < ST_NLSTM; ++i) psize_lstm += p.size[i];
+    int psize = psize_lstm;
+    for (int i = ST_NLSTM; i < SUR_ST_NPARAM; ++i) psize += p.size[i];
+    float* row = p.partial + (size_t)(row_base + b) * psize;
+    float* gacc = grads_in_lds ? wbase + psize_lstm : row;
+    float* g[SUR_ST_NPARAM];
+    {
+        int off = 0;
+        for (int i = 0; i < ST_NLSTM; ++i) {
+            g[i] = gacc + off;
+            off += p.size[i];
+        }
+        if (grads_in_lds)
+            for (int j = threadIdx.x; j < psize_lstm; j += blockDim.x) gacc[j] = 0.0f;
+    }
     for (int i = threadIdx.x; i < s; i += blockDim.x) L.dh_carry[i] = L.dc_carry[i] = 0.0f;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) L.dout_carry[i] = 0.0f;
     __syncthreads();
 
     for (int k = K - 1; k >= 0; --k) {
         const size_t kb = (size_t)k * B + b;
-        // ---- reload this step's inputs and recompute its forward intermediates ----
         for (int i = threadIdx.x; i < nx; i += blockDim.x) L.x[i] = xlat_t[kb * nx + i];
         for (int i = threadIdx.x; i < s; i += blockDim.x) {
             const size_t prev = ((size_t)(k - 1) * B + b) * s + i;
             L.h[i] = (k < S) ? lstates_t[kb * s + i] : (k > 0 ? h_all[prev] : h0[(size_t)b * s + i]);
             L.c[i] = (k > 0) ? c_all[prev] : c0[(size_t)b * s + i];
         }
-        if (direct) fetch_block(k, L.blk[0]);  // retired by the barrier below
-        if (staged) {
-            const float4* src = reinterpret_cast<const float4*>(L.blk[1]);
-            float4* dst = reinterpret_cast<float4*>(L.blk[0]);
-            for (int i = threadIdx.x; i < nblock4; i += blockDim.x) dst[i] = src[i];
+        {   // the DMA of this step's [gates | c_k] was retired by the previous phase-closing barrier
+            const float4* src = reinterpret_cast<const float4*>(next_blk);
+            float4* dst = reinterpret_cast<float4*>(L.gates);
+            for (int i = threadIdx.x; i < (5 * s) >> 2; i += blockDim.x) dst[i] = src[i];
         }
         __syncthreads();
-        STAMP(20);
-        if (!staged && !direct) step_forward_body(p, L, w);
-        STAMP(21);
-
-        // ---- total gradient wrt d_k: direct + through out_k = base + delta*(d*mul + add) ----
-        for (int i = threadIdx.x; i < n; i += blockDim.x) {
-            const float go = (dout_all ? dout_all[kb * n + i] : 0.0f) + L.dout_carry[i];
-            L.gA[i] = fmaf(p.delta * p.mul, go, dd_all ? dd_all[kb * n + i] : 0.0f);
-            // out_{k-1} is the base of step k only while free running
-            L.dout_carry[i] = (k >= S) ? go : 0.0f;
-        }
-        __syncthreads();
-        STAMP(22);
-        // ---- decoder backward ----
-        conv_bwd_weight<5>(L.gA, 1, L.a2, 1, n, 1, 2, g[SUR_ST_CV3_W], g[SUR_ST_CV3_B], all_waves(), false);
-        STAMP(12);
-        conv_bwd_data<5>(L.gA, 1, n, w[SUR_ST_CV3_W], 1, 1, 2, L.gB, false);
-        STAMP(13);
-        act_ln_bwd(L.gB, L.p2, 1, n, w[SUR_ST_LN2_W], true, L.gA, L.xh, g[SUR_ST_LN2_W], g[SUR_ST_LN2_B]);
-        STAMP(14);
-        conv_bwd_weight<7>(L.gA, 1, L.a1, p.c_mid, n, 1, 3, g[SUR_ST_CV2_W], g[SUR_ST_CV2_B], all_waves(), false);
-        STAMP(15);
-        conv_bwd_data<7>(L.gA, 1, n, w[SUR_ST_CV2_W], p.c_mid, 1, 3, L.gB, false);
-        STAMP(16);
-        act_ln_bwd(L.gB, L.p1, p.c_mid, n, w[SUR_ST_LN1_W], true, L.gA, L.xh, g[SUR_ST_LN1_W], g[SUR_ST_LN1_B]);
-        STAMP(17);
-        deconv_bwd_weight(L.gA, p.c_mid, L.a0, p.cs, 2 * p.hq, g[SUR_ST_DC1_W], g[SUR_ST_DC1_B], lower_half(), false);
-        STAMP(18);
-        deconv_bwd_data(L.gA, p.c_mid, 2 * p.hq, w[SUR_ST_DC1_W], p.cs, L.gB, upper_half(), true);
-        STAMP(19);
-        act_ln_bwd(L.gB, L.p0, p.cs, 2 * p.hq, w[SUR_ST_LN0_W], true, L.gA, L.xh, g[SUR_ST_LN0_W], g[SUR_ST_LN0_B]);
-        STAMP(26);
-        deconv_bwd_weight(L.gA, p.cs, L.hnew, p.cs, p.hq, g[SUR_ST_DC0_W], g[SUR_ST_DC0_B], lower_half(), false);
-        STAMP(27);
-        deconv_bwd_data(L.gA, p.cs, p.hq, w[SUR_ST_DC0_W], p.cs, L.dh, upper_half(), true);
-
-        STAMP(23);
-        // ---- cell backward ----
         for (int i = threadIdx.x; i < s; i += blockDim.x) {
-            const float dhn = L.dh[i] + L.dh_carry[i] + (dh_all ? dh_all[kb * s + i] : 0.0f);
+            const float dhn = dh_dec[kb * s + i] + L.dh_carry[i] + (dh_all ? dh_all[kb * s + i] : 0.0f);
             const float gi = L.gates[i], gf = L.gates[s + i], gg = L.gates[2 * s + i], go = L.gates[3 * s + i];
             const float tc = tanhf(L.cnew[i]);
             const float dcn = L.dc_carry[i] + (dc_all ? dc_all[kb * s + i] : 0.0f) + dhn * go * (1.0f - tc * tc);
@@ -1215,91 +1401,8 @@ chunk_bwd_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, con
             L.dc_carry[i] = dcn * gf;  // gradient wrt c_{k-1}
         }
         __syncthreads();
-        STAMP(24);
-        if (staged && k > 0) fetch_block(k - 1, L.blk[1]);
-        {
-            // four independent GEMMs on the gate gradients dG [4*cs][hq], issued without barriers in between:
-            //   dx  [ca][hq]  = sum_g Wx_g^T * dG_g     (waves: first quarter)
-            //   dh  [cs][hq]  = sum_g Wh_g^T * dG_g     (second quarter)
-            //   gWx, gWh, gb  = dG_g x {x, h}           (second half)
-            const int nwg = blockDim.x >> 6, cs = p.cs, ca = p.ca, hq = p.hq;
-            const int gate_stride = (int)(w[SUR_ST_WXF] - w[SUR_ST_WXI]);
-            const WaveSet w_dx = nwg >= 4 ? WaveSet{0, nwg / 4} : all_waves();
-            const WaveSet w_dh = nwg >= 4 ? WaveSet{nwg / 4, nwg / 4} : all_waves();
-            const WaveSet w_gw = nwg >= 4 ? WaveSet{nwg / 2, nwg - nwg / 2} : all_waves();
-            auto tap_col = [&](int, int tap, int j) { return wrapi(j - tap + 1, hq); };  // stride 1, pad 1
-            {   // A[m=ci][c=o][tap] = W_g[(o*cin + ci)*3 + tap];  B = dG_g[o][col]
-                const float* wx = w[SUR_ST_WXI];
-                const GemmSeg sx[4] = {{wx, 3, ca * 3, L.dgates, hq, cs},
-                                       {wx + gate_stride, 3, ca * 3, L.dgates + s, hq, cs},
-                                       {wx + 2 * gate_stride, 3, ca * 3, L.dgates + 2 * s, hq, cs},
-                                       {wx + 3 * gate_stride, 3, ca * 3, L.dgates + 3 * s, hq, cs}};
-                float* dxp = L.dx;
-                gemm_taps<3, 4>(w_dx, false, ca, hq, sx, tap_col, [&](int m, int j, float v) {
-                    if (m < ca) dxp[m * hq + j] = v;
-                });
-                STAMP(28);
-                const float* wh = w[SUR_ST_WHI];
-                const GemmSeg sh[4] = {{wh, 3, cs * 3, L.dgates, hq, cs},
-                                       {wh + gate_stride, 3, cs * 3, L.dgates + s, hq, cs},
-                                       {wh + 2 * gate_stride, 3, cs * 3, L.dgates + 2 * s, hq, cs},
-                                       {wh + 3 * gate_stride, 3, cs * 3, L.dgates + 3 * s, hq, cs}};
-                float* dhp = L.dhin;
-                gemm_taps<3, 4>(w_dh, false, cs, hq, sh, tap_col, [&](int m, int j, float v) {
-                    if (m < cs) dhp[m * hq + j] = v;
-                });
-                STAMP(29);
-            }
-            // weight gradients, all gates in one GEMM each: rows m = (gate, o)
-            struct St { const float* row; int off; };
-            {
-                float* gx = g[SUR_ST_WXI];
-                const float* xin = L.x;
-                const int ncols = ca * 3;
-                gemm_pos(w_gw, false, 4 * cs, ncols, hq, L.dgates, hq,
-                         [&](int n) { const int ci = n / 3, k = n - ci * 3; return St{xin + ci * hq, k - 1}; },
-                         [&](const St& st, int pp) { return st.row[wrapi(pp + st.off, hq)]; },
-                         [&](int m, int n, float v) {
-                             if (m < 4 * cs && n < ncols) {
-                                 const int gt = m / cs, o = m - gt * cs;
-                                 gx[gt * gate_stride + o * ncols + n] += v;
-                             }
-                         });
-                STAMP(30);
-                float* gh = g[SUR_ST_WHI];
-                const float* hin_ = L.h;
-                const int ncols_h = cs * 3;
-                // the dx / dh waves finish well before the two weight-gradient waves: they take the last third of
-                // the gWh tiles (measured alone: dx 10.6 k, dh 9.1 k, gWx + gWh 18.7 k cycles on two waves)
-                const int th_all = ((4 * cs + 15) >> 4) * ((ncols_h + 15) >> 4), th_split = nwg >= 4 ? (2 * th_all) / 3 : th_all;
-                auto gwh = [&](WaveSet wset, int lo, int hi) {
-                    gemm_pos(wset, false, 4 * cs, ncols_h, hq, L.dgates, hq,
-                             [&](int n) { const int ci = n / 3, k = n - ci * 3; return St{hin_ + ci * hq, k - 1}; },
-                             [&](const St& st, int pp) { return st.row[wrapi(pp + st.off, hq)]; },
-                             [&](int m, int n, float v) {
-                                 if (m < 4 * cs && n < ncols_h) {
-                                     const int gt = m / cs, o = m - gt * cs;
-                                     gh[gt * gate_stride + o * ncols_h + n] += v;
-                                 }
-                             }, lo, hi);
-                };
-                gwh(w_gw, 0, th_split);
-                if (th_split < th_all) gwh(WaveSet{0, nwg / 2}, th_split, th_all);
-                STAMP(31);
-                float* gbx = g[SUR_ST_BXI];
-                for (int idx = threadIdx.x; idx < 4 * cs; idx += blockDim.x) {
-                    const int gt = idx / cs, o = idx - gt * cs;
-                    float a0 = 0.0f, a1 = 0.0f;
-                    for (int pp = 0; pp < hq; pp += 2) {
-                        a0 += L.dgates[idx * hq + pp];
-                        a1 += L.dgates[idx * hq + pp + 1];
-                    }
-                    gbx[gt * gate_stride + o] += a0 + a1;
-                }
-            }
-            __syncthreads();
-        }
-        STAMP(25);
+        if (k > 0) fetch_block(k - 1);
+        cell_backward_gemms(p, L, w, g);
         if (dxlat_t)
             for (int i = threadIdx.x; i < nx; i += blockDim.x) dxlat_t[kb * nx + i] = L.dx[i];
         for (int i = threadIdx.x; i < s; i += blockDim.x) {
@@ -1319,7 +1422,7 @@ chunk_bwd_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, con
     }
     if (grads_in_lds) {
         __syncthreads();
-        add_to_row(row, gacc, psize);
+        add_to_row(row, gacc, psize_lstm);
     }
 }
 
@@ -1439,10 +1542,9 @@ int sur_flush_encoder_grads(void* stream, const sur_encoder_params* p) {
 
 int sur_chunk_saved_floats(const sur_chunk_params* p) {
     if (!p) return 0;
-    // float4 granularity of the block and of its LDS position; the padded block must fit in the backward kernel's LDS
-    if ((p->hq & 3) || ((p->ca * p->hq) & 3)) return 0;
-    const size_t lds = sizeof(float) * (step_act_floats(*p, true, 1) + psize_of<SUR_ST_NPARAM>(p->size));
-    return lds <= LDS_LIMIT ? step_saved_floats(*p) : 0;
+    // the GEMM tiles want whole 16-wide latent rows; the cell backward moves [gates | c] in whole 1 KiB DMA pieces
+    if ((p->hq & 15) || ((p->ca * p->hq) & 3) || (5 * p->cs * p->hq) % DMA_PIECE) return 0;
+    return step_saved_floats(*p);
 }
 
 int sur_chunk_forward(void* stream, const sur_chunk_params* p, const float* xlat_t, const float* lstates_t,
@@ -1452,39 +1554,84 @@ int sur_chunk_forward(void* stream, const sur_chunk_params* p, const float* xlat
         !lstates_t || !states_t)
         return fail(-1, "sur_chunk_forward: bad argument (need K > 0, B > 0, S >= 1)");
     if (4 * p->hq > 64 * LN_MAX_EPL) return fail(-4, "sur_chunk_forward: N = %d too wide for the fused LayerNorm", 4 * p->hq);
-    const int psize = psize_of<SUR_ST_NPARAM>(p->size);
-    const size_t lds = sizeof(float) * (step_act_floats(*p, false) + psize);
+    if (p->hq & 15) return fail(-4, "sur_chunk_forward: latent width N/4 = %d must be a multiple of 16", p->hq);
     if (saved && sur_chunk_saved_floats(p) == 0)
-        return fail(-4, "sur_chunk_forward: this geometry has no saved-activation path (pass saved = NULL)");
-    if (int rc = set_lds(chunk_fwd_kernel, lds, "chunk forward")) return rc;
+        return fail(-4, "sur_chunk_forward: hq = %d, ca = %d, cs = %d: no `saved` buffer for this geometry", p->hq, p->ca, p->cs);
+    // split path: the cell chain (one workgroup per sample), then the decoders of all (step, sample) pairs in
+    // parallel, then the integration of the predicted deltas
+    int psize_lstm = 0, psize_dec = 0;
+    for (int i = 0; i < ST_NLSTM; ++i) psize_lstm += p->size[i];
+    for (int i = ST_NLSTM; i < SUR_ST_NPARAM; ++i) psize_dec += p->size[i];
+    const size_t lds_cell = sizeof(float) * (cell_fwd_act_floats(*p) + psize_lstm);
+    const size_t lds_dec = sizeof(float) * (dec_act_floats(*p, false) + psize_dec);
+    if (int rc = set_lds(cell_fwd_kernel, lds_cell, "cell forward")) return rc;
+    if (int rc = set_lds(dec_fwd_kernel, lds_dec, "decoder forward")) return rc;
+    const int m = k * b, n = 4 * p->hq;
+    if (int rc = launch_checked([&] {
+            hipLaunchKernelGGL(cell_fwd_kernel, dim3(b), dim3(TPB), lds_cell, (hipStream_t)stream, *p, xlat_t, lstates_t, h0, c0, k,
+                               s, b, h_all, c_all, saved);
+        }, "cell_fwd")) return rc;
+    if (int rc = launch_checked([&] {
+            hipLaunchKernelGGL(dec_fwd_kernel, dim3(m < 1024 ? m : 1024), dim3(TPB), lds_dec, (hipStream_t)stream, *p, h_all, m,
+                               d_all, saved);
+        }, "dec_fwd")) return rc;
     return launch_checked([&] {
-        hipLaunchKernelGGL(chunk_fwd_kernel, dim3(b), dim3(TPB), lds, (hipStream_t)stream, *p, xlat_t, lstates_t, states_t, h0,
-                           c0, k, s, b, h_all, c_all, d_all, out_all, saved);
-    }, "chunk_fwd");
+        hipLaunchKernelGGL(integrate_kernel, dim3((b * n + TPB - 1) / TPB), dim3(TPB), 0, (hipStream_t)stream, states_t, d_all, k,
+                           s, b, n, p->delta, p->mul, p->add, out_all);
+    }, "integrate");
+}
+
+int sur_chunk_workspace_floats(const sur_chunk_params* p, int k, int b) {
+    if (!p || k <= 0 || b <= 0) return 0;
+    return k * b * (p->cs * p->hq + 4 * p->hq);   // dh_dec [K,B,cs,hq] + ga_all [K,B,1,N]
 }
 
 int sur_chunk_backward(void* stream, const sur_chunk_params* p, const float* xlat_t, const float* lstates_t,
                        const float* h0, const float* c0, const float* h_all, const float* c_all, const float* dd_all,
                        const float* dout_all, const float* dh_all, const float* dc_all, int k, int s, int b,
-                       float* dxlat_t, float* dlstates_t, float* dh0, float* dc0, int row_base, const float* saved) {
+                       float* dxlat_t, float* dlstates_t, float* dh0, float* dc0, int row_base, int row_count,
+                       const float* saved, float* workspace) {
     if (!p || !xlat_t || !lstates_t || !h0 || !c0 || !h_all || !c_all || k <= 0 || b <= 0 || s < 1)
         return fail(-1, "sur_chunk_backward: bad argument");
-    if (saved && sur_chunk_saved_floats(p) == 0)
-        return fail(-4, "sur_chunk_backward: this geometry has no saved-activation path (pass saved = NULL)");
-    if (!p->partial || row_base < 0 || p->rows < row_base + b)
-        return fail(-1, "sur_chunk_backward: partial gradient buffer has %d rows, need [%d, %d)", p->rows, row_base, row_base + b);
-    const int psize = psize_of<SUR_ST_NPARAM>(p->size);
-    int save_mode = 0;
-    if (saved) save_mode = sizeof(float) * (step_act_floats(*p, true, 2) + psize) <= LDS_LIMIT ? 2 : 1;
-    const size_t base = sizeof(float) * (step_act_floats(*p, true, save_mode) + psize);
-    int grads_in_lds = (base + sizeof(float) * psize <= LDS_LIMIT) ? 1 : 0;
-    const size_t lds = base + (grads_in_lds ? sizeof(float) * psize : 0);
-    if (int rc = set_lds(chunk_bwd_kernel, lds, "chunk backward")) return rc;
-    return launch_checked([&] {
-        hipLaunchKernelGGL(chunk_bwd_kernel, dim3(b), dim3(TPB), lds, (hipStream_t)stream, *p, xlat_t, lstates_t, h0, c0, h_all,
-                           c_all, dd_all, dout_all, dh_all, dc_all, k, s, b, dxlat_t, dlstates_t, dh0, dc0, grads_in_lds, row_base,
-                           saved, save_mode);
-    }, "chunk_bwd");
+    if (!saved || !workspace)
+        return fail(-1, "sur_chunk_backward: needs the `saved` buffer sur_chunk_forward filled and a workspace");
+    if (sur_chunk_saved_floats(p) == 0)
+        return fail(-4, "sur_chunk_backward: hq = %d, ca = %d, cs = %d: geometry not supported", p->hq, p->ca, p->cs);
+    if (!p->partial || row_base < 0 || row_count < b || p->rows < row_base + row_count)
+        return fail(-1, "sur_chunk_backward: partial gradient buffer has %d rows, need [%d, %d) with at least B = %d of them",
+                    p->rows, row_base, row_base + row_count, b);
+    {   // decoder backward of all (step, sample) pairs in parallel, then the cell chain per sample
+        int psize_lstm = 0, psize_dec = 0;
+        for (int i = 0; i < ST_NLSTM; ++i) psize_lstm += p->size[i];
+        for (int i = ST_NLSTM; i < SUR_ST_NPARAM; ++i) psize_dec += p->size[i];
+        const int m = k * b, n = 4 * p->hq, sl = p->cs * p->hq;
+        float* dh_dec = workspace;
+        float* ga_all = workspace + (size_t)m * sl;
+        const float* ga = dd_all;
+        if (dout_all || !dd_all) {
+            if (int rc = launch_checked([&] {
+                    hipLaunchKernelGGL(dgrad_scan_kernel, dim3((b * n + TPB - 1) / TPB), dim3(TPB), 0, (hipStream_t)stream, dd_all,
+                                       dout_all, k, s, b, n, p->delta * p->mul, ga_all);
+                }, "dgrad_scan")) return rc;
+            ga = ga_all;
+        }
+        const size_t dec_base = sizeof(float) * (dec_act_floats(*p, true) + psize_dec);
+        const int dec_gl = dec_base + sizeof(float) * psize_dec <= LDS_LIMIT ? 1 : 0;
+        const size_t lds_dec = dec_base + (dec_gl ? sizeof(float) * psize_dec : 0);
+        const size_t cell_base = sizeof(float) * (cell_bwd_act_floats(*p) + psize_lstm);
+        const int cell_gl = cell_base + sizeof(float) * psize_lstm <= LDS_LIMIT ? 1 : 0;
+        const size_t lds_cell = cell_base + (cell_gl ? sizeof(float) * psize_lstm : 0);
+        if (int rc = set_lds(dec_bwd_kernel, lds_dec, "decoder backward")) return rc;
+        if (int rc = set_lds(cell_bwd_kernel, lds_cell, "cell backward")) return rc;
+        if (int rc = launch_checked([&] {
+                hipLaunchKernelGGL(dec_bwd_kernel, dim3(m < row_count ? m : row_count), dim3(TPB), lds_dec, (hipStream_t)stream, *p,
+                                   saved, ga, m, dh_dec, dec_gl, row_base);
+            }, "dec_bwd")) return rc;
+        return launch_checked([&] {
+            hipLaunchKernelGGL(cell_bwd_kernel, dim3(b), dim3(TPB), lds_cell, (hipStream_t)stream, *p, xlat_t, lstates_t, h0, c0,
+                               h_all, c_all, saved, dh_dec, dh_all, dc_all, k, s, b, dxlat_t, dlstates_t, dh0, dc0, cell_gl, row_base);
+        }, "cell_bwd");
+    }
 }
 
 int sur_flush_chunk_grads(void* stream, const sur_chunk_params* p) {

@@ -46,8 +46,9 @@ SYMBOLS = (
     ("sur_flush_encoder_grads", [_fp, _EP]),
     ("sur_chunk_saved_floats", [_CP]),
     ("sur_chunk_forward", [_fp, _CP, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _fp, _fp, _fp, _fp, _fp]),
+    ("sur_chunk_workspace_floats", [_CP, _i, _i]),
     ("sur_chunk_backward", [_fp, _CP, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _fp, _fp, _fp, _fp,
-                            _i, _fp]),
+                            _i, _i, _fp, _fp]),
     ("sur_flush_chunk_grads", [_fp, _CP]),
     ("sur_tbptt_delta_loss", [_fp, _fp, _fp, _i, _i, _i, ctypes.c_float, ctypes.c_float, ctypes.c_float, _fp, _fp, _fp, _fp,
                               _fp, _fp, _fp]),
@@ -132,6 +133,8 @@ class _Pack:
 # one partial row per workgroup of the encoder backward: two workgroups per CU (the kernel is built for 2 waves per
 # SIMD) hide each other's dependent-phase latency
 ENCODER_ROWS = 512
+# partial rows of one chunk backward launch: the parallel decoder backward runs one workgroup per row
+CHUNK_ROWS = 256
 
 
 def _encoder_pack(convnet, n):
@@ -317,7 +320,7 @@ class _EncoderFn(torch.autograd.Function):
         return dx, None, None, None
 
 
-SAVE_ACTIVATIONS = True   # False: the backward kernel recomputes each step's forward (bit-identical, slower)
+SAVE_ACTIVATIONS = True   # False: the ENCODER backward recomputes its forward (bit-identical, slower; test hook)
 
 
 def _encoder_saved_buffer(pack, m, device):
@@ -326,11 +329,19 @@ def _encoder_saved_buffer(pack, m, device):
     return torch.empty((m, f), device=device, dtype=torch.float32) if f > 0 else None
 
 
+def _chunk_workspace(pack, k, b, device):
+    """Scratch of the chunk backward's split path (per-step decoder gradients wrt h and wrt the predicted deltas)."""
+    f = load().sur_chunk_workspace_floats(ctypes.byref(pack.c), k, b)
+    return torch.empty(f, device=device, dtype=torch.float32)
+
+
 def _saved_buffer(pack, k, b, device):
-    """[K, B, F] buffer for the forward intermediates the backward kernel streams back instead of recomputing
-    (None if the library has no saved-activation path for this geometry)."""
-    f = load().sur_chunk_saved_floats(ctypes.byref(pack.c)) if SAVE_ACTIVATIONS else 0
-    return torch.empty((k, b, f), device=device, dtype=torch.float32) if f > 0 else None
+    """[K, B, F] buffer for the forward intermediates of a chunk: the backward kernels (parallel decoder backward +
+    cell chain) read them back instead of recomputing the steps."""
+    f = load().sur_chunk_saved_floats(ctypes.byref(pack.c))
+    if f <= 0:
+        raise SurrogateHipError("the fused chunk kernels need a latent width N/4 that is a multiple of 16 (N = 64, 128, 256)")
+    return torch.empty((k, b, f), device=device, dtype=torch.float32)
 
 
 class _ChunkFn(torch.autograd.Function):
@@ -368,10 +379,14 @@ class _ChunkFn(torch.autograd.Function):
         dh0 = torch.empty_like(h0) if nh else None
         dc0 = torch.empty_like(c0) if nc else None
         k, b = xlat_t.shape[:2]
+        rows = max(b, CHUNK_ROWS)
+        ctx.pack.ensure_rows(rows)
+        ctx.owner.refresh_partials()
+        work = _chunk_workspace(ctx.pack, k, b, xlat_t.device) if ctx.fwd_saved is not None else None
         _check(load().sur_chunk_backward(_stream(), ctypes.byref(ctx.pack.c), _p(xlat_t), _p(lstates_t), _p(h0), _p(c0),
                                          _p(h_all), _p(c_all), _p(dd_all), _p(dout_all), _p(dh_all), _p(dc_all), k,
-                                         lstates_t.shape[0], b, _p(dxlat), _p(dlst), _p(dh0), _p(dc0), 0,
-                                         _p(ctx.fwd_saved)))
+                                         lstates_t.shape[0], b, _p(dxlat), _p(dlst), _p(dh0), _p(dc0), 0, rows,
+                                         _p(ctx.fwd_saved), _p(work)))
         ctx.fwd_saved = None
         ctx.pack.dirty = True
         ctx.owner.schedule_flush()
@@ -595,7 +610,8 @@ class _TBPTTFn(torch.autograd.Function):
             return (None,) * 7
         dd_all = dd_all.contiguous()
         dxlat_all = torch.empty_like(lactions_t)
-        owner.chunk.ensure_rows(nchunks * b)
+        rows = max(b, CHUNK_ROWS)
+        owner.chunk.ensure_rows(nchunks * rows)
         enc_rows = [min(ENCODER_ROWS, ls.shape[0] * b) for ls in lstates]
         owner.state_enc.ensure_rows(sum(enc_rows))
         owner.refresh_partials()
@@ -605,10 +621,14 @@ class _TBPTTFn(torch.autograd.Function):
             fork = _Fork(streams[c])
             with fork:
                 dlst = torch.empty_like(lstates[c])
+                work = _chunk_workspace(owner.chunk, k1 - k0, b, dev) if saveds[c] is not None else None
                 _check(lib.sur_chunk_backward(_stream(), ctypes.byref(owner.chunk.c), _p(lactions_t[k0:k1]), _p(lstates[c]),
                                               _p(h0s[c]), _p(c0s[c]), _p(h_alls[c]), _p(c_alls[c]), _p(dd_all[k0:k1]), None,
                                               None, None, k1 - k0, min(seeds[c].shape[0], k1 - k0), b,
-                                              _p(dxlat_all[k0:k1]), _p(dlst), None, None, c * b, _p(saveds[c])))
+                                              _p(dxlat_all[k0:k1]), _p(dlst), None, None, c * rows, rows, _p(saveds[c]),
+                                              _p(work)))
+                if work is not None:
+                    work.record_stream(fork.stream)
                 if fork.forked:
                     # the action-encoder backward below only needs the chunks' dxlat: it must not wait for the
                     # state-encoder backward that follows on this side stream

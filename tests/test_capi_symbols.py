@@ -70,7 +70,8 @@ def test_surrogate_abi_rejects_bad_arguments_before_touching_the_device():
     assert lib.sur_chunk_forward(null, ctypes.byref(chunk), null, null, null, null, null, 0, 1, 1, null, null, null, null, null) < 0
     assert b"sur_chunk_forward" in lib.sur_last_error()
     assert lib.sur_chunk_backward(null, ctypes.byref(chunk), null, null, null, null, null, null, null, null, null, null, 1, 1,
-                                  1, null, null, null, null, 0, null) < 0
+                                  1, null, null, null, null, 0, 1, null, null) < 0
+    assert lib.sur_chunk_workspace_floats(ctypes.byref(chunk), 0, 4) == 0
     assert lib.sur_flush_encoder_grads(null, ctypes.byref(enc)) < 0      # no partial buffer
     assert lib.sur_flush_chunk_grads(null, ctypes.byref(chunk)) < 0
     assert lib.sur_tbptt_delta_loss(null, null, null, 1, 2, 64, 0.25, 0.0, 1.0, null, null, null, null, null, null, null) < 0
@@ -81,9 +82,10 @@ def test_surrogate_abi_rejects_bad_arguments_before_touching_the_device():
     for i, n in enumerate(sizes):
         chunk.size[i] = n
     assert lib.sur_chunk_saved_floats(ctypes.byref(chunk)) == 3840        # 3 712 floats padded to 1 KiB DMA pieces
+    assert lib.sur_chunk_workspace_floats(ctypes.byref(chunk), 10, 64) == 10 * 64 * (256 + 64)
     chunk.hq = 64                                                        # N = 256: one padded copy still fits
     assert lib.sur_chunk_saved_floats(ctypes.byref(chunk)) == 14848
-    chunk.hq = 62                                                        # not float4-aligned: no saved path
+    chunk.hq = 8                                                         # N = 32: latent rows narrower than a GEMM tile
     assert lib.sur_chunk_saved_floats(ctypes.byref(chunk)) == 0
     enc.n, enc.c[0], enc.c[1], enc.c[2], enc.c[3] = 64, 1, 8, 16, 16
     enc.stride[0], enc.stride[1], enc.stride[2] = 2, 2, 1

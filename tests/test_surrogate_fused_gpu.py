@@ -77,10 +77,10 @@ def test_fused_encoder_forward_backward(dev, which, N):
 
 
 @pytest.mark.parametrize("N", [64, 256])
-@pytest.mark.parametrize("K,S", [(1, 1), (4, 2), (3, 1)])
+@pytest.mark.parametrize("K,S", [(1, 1), (4, 2), (3, 1), (5, 5)])
 def test_fused_chunk_forward_backward(dev, N, K, S):
-    """K rollout steps (S teacher forced) in one launch vs the same steps composed from torch modules,
-    with upstream gradients on every output (h_all, c_all, d_all, out_all)."""
+    """K rollout steps (S teacher forced) -- cell chain, parallel decoders, integration -- vs the same steps composed
+    from torch modules, with upstream gradients on every output (h_all, c_all, d_all, out_all)."""
     from pdecontrol.surrogates import hipops
     m = _build(dev, N=N)
     sur = m.surrogate
@@ -208,8 +208,8 @@ def test_ensemble_parallel_step_equals_member_by_member(dev):
 
 
 @pytest.mark.parametrize("N", [64, 256])
-def test_saved_activations_backward_is_bit_identical_to_recompute(dev, N, monkeypatch):
-    """sur_chunk_backward fed with the forward's saved intermediates == recomputing them in the kernel."""
+def test_encoder_saved_activations_backward_is_bit_identical_to_recompute(dev, N, monkeypatch):
+    """enc_bwd fed with the forward's saved intermediates == recomputing them in the kernel."""
     from pdecontrol.surrogates import hipops, ops
     g = torch.Generator().manual_seed(3)
     states = (torch.rand(8, 20, 1, N, generator=g) * 2 - 1).to(dev)
