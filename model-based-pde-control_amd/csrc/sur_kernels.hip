@@ -1030,91 +1030,88 @@ __device__ void decoder_backward(const sur_chunk_params& p, const StepLayout& L,
 
 }
 
-// cell backward GEMMs on LDS-resident gate gradients L.dgates: L.dx, L.dhin and the LSTM weight / bias gradients
-__device__ void cell_backward_gemms(const sur_chunk_params& p, const StepLayout& L, const float* const* w, float* const* g) {
-    const int s = p.cs * p.hq;
+// Cell backward, recurrent part: dh_in [cs][hq] = sum_g Wh_g^T * dG_g.  The K = 4 * cs * 3 contraction is split by gate
+// over the wave quarters (each writes its partial tile to part[g]); the caller adds the four partials.
+__device__ void cell_dh_gemm(const sur_chunk_params& p, const StepLayout& L, const float* const* w, float* part) {
+    const int s = p.cs * p.hq, nwg = blockDim.x >> 6, cs = p.cs, hq = p.hq;
+    const int gate_stride = (int)(w[SUR_ST_WXF] - w[SUR_ST_WXI]);
+    auto tap_col = [&](int, int tap, int j) { return wrapi(j - tap + 1, hq); };  // stride 1, pad 1
+    const float* wh = w[SUR_ST_WHI];
+    for (int gt = 0; gt < 4; ++gt) {   // A[m=ci][c=o][tap] = W_g[(o*cin + ci)*3 + tap];  B = dG_g[o][col]
+        const GemmSeg sh[1] = {{wh + gt * gate_stride, 3, cs * 3, L.dgates + gt * s, hq, cs}};
+        float* dst = part + gt * s;
+        const WaveSet ws = nwg >= 4 ? WaveSet{gt * (nwg / 4), nwg / 4} : all_waves();
+        gemm_taps<3, 1>(ws, false, cs, hq, sh, tap_col, [&](int m, int j, float v) {
+            if (m < cs) dst[m * hq + j] = v;
+        });
+    }
+    __syncthreads();
+}
+
+// Cell backward, non-recurrent part for one (step, sample): dx [ca][hq] = sum_g Wx_g^T * dG_g and the LSTM weight /
+// bias gradients dG_g x {x, h_in}.  dx on the first wave, the weight-gradient tiles on the others.
+__device__ void cell_wgrad_gemms(const sur_chunk_params& p, const StepLayout& L, const float* const* w, float* const* g) {
+    const int s = p.cs * p.hq, nwg = blockDim.x >> 6, cs = p.cs, ca = p.ca, hq = p.hq;
+    const int gate_stride = (int)(w[SUR_ST_WXF] - w[SUR_ST_WXI]);
+    const WaveSet w_dx = nwg >= 4 ? WaveSet{0, 1} : all_waves();
+    const WaveSet w_gw = nwg >= 4 ? WaveSet{1, nwg - 1} : all_waves();
+    auto tap_col = [&](int, int tap, int j) { return wrapi(j - tap + 1, hq); };
     {
-        // four independent GEMMs on the gate gradients dG [4*cs][hq], issued without barriers in between:
-        //   dx  [ca][hq]  = sum_g Wx_g^T * dG_g     (waves: first quarter)
-        //   dh  [cs][hq]  = sum_g Wh_g^T * dG_g     (second quarter)
-        //   gWx, gWh, gb  = dG_g x {x, h}           (second half)
-        const int nwg = blockDim.x >> 6, cs = p.cs, ca = p.ca, hq = p.hq;
-        const int gate_stride = (int)(w[SUR_ST_WXF] - w[SUR_ST_WXI]);
-        const WaveSet w_dx = nwg >= 4 ? WaveSet{0, nwg / 4} : all_waves();
-        const WaveSet w_dh = nwg >= 4 ? WaveSet{nwg / 4, nwg / 4} : all_waves();
-        const WaveSet w_gw = nwg >= 4 ? WaveSet{nwg / 2, nwg - nwg / 2} : all_waves();
-        auto tap_col = [&](int, int tap, int j) { return wrapi(j - tap + 1, hq); };  // stride 1, pad 1
-        {   // A[m=ci][c=o][tap] = W_g[(o*cin + ci)*3 + tap];  B = dG_g[o][col]
-            const float* wx = w[SUR_ST_WXI];
-            const GemmSeg sx[4] = {{wx, 3, ca * 3, L.dgates, hq, cs},
-                                   {wx + gate_stride, 3, ca * 3, L.dgates + s, hq, cs},
-                                   {wx + 2 * gate_stride, 3, ca * 3, L.dgates + 2 * s, hq, cs},
-                                   {wx + 3 * gate_stride, 3, ca * 3, L.dgates + 3 * s, hq, cs}};
-            float* dxp = L.dx;
-            gemm_taps<3, 4>(w_dx, false, ca, hq, sx, tap_col, [&](int m, int j, float v) {
-                if (m < ca) dxp[m * hq + j] = v;
-            });
-            STAMP(28);
-            const float* wh = w[SUR_ST_WHI];
-            const GemmSeg sh[4] = {{wh, 3, cs * 3, L.dgates, hq, cs},
-                                   {wh + gate_stride, 3, cs * 3, L.dgates + s, hq, cs},
-                                   {wh + 2 * gate_stride, 3, cs * 3, L.dgates + 2 * s, hq, cs},
-                                   {wh + 3 * gate_stride, 3, cs * 3, L.dgates + 3 * s, hq, cs}};
-            float* dhp = L.dhin;
-            gemm_taps<3, 4>(w_dh, false, cs, hq, sh, tap_col, [&](int m, int j, float v) {
-                if (m < cs) dhp[m * hq + j] = v;
-            });
-            STAMP(29);
-        }
-        // weight gradients, all gates in one GEMM each: rows m = (gate, o)
-        struct St { const float* row; int off; };
-        {
-            float* gx = g[SUR_ST_WXI];
-            const float* xin = L.x;
-            const int ncols = ca * 3;
-            gemm_pos(w_gw, false, 4 * cs, ncols, hq, L.dgates, hq,
-                     [&](int n) { const int ci = n / 3, k = n - ci * 3; return St{xin + ci * hq, k - 1}; },
-                     [&](const St& st, int pp) { return st.row[wrapi(pp + st.off, hq)]; },
-                     [&](int m, int n, float v) {
-                         if (m < 4 * cs && n < ncols) {
-                             const int gt = m / cs, o = m - gt * cs;
-                             gx[gt * gate_stride + o * ncols + n] += v;
-                         }
-                     });
-            STAMP(30);
-            float* gh = g[SUR_ST_WHI];
-            const float* hin_ = L.h;
-            const int ncols_h = cs * 3;
-            // the dx / dh waves finish well before the two weight-gradient waves: they take the last third of
-            // the gWh tiles (measured alone: dx 10.6 k, dh 9.1 k, gWx + gWh 18.7 k cycles on two waves)
-            const int th_all = ((4 * cs + 15) >> 4) * ((ncols_h + 15) >> 4), th_split = nwg >= 4 ? (2 * th_all) / 3 : th_all;
-            auto gwh = [&](WaveSet wset, int lo, int hi) {
-                gemm_pos(wset, false, 4 * cs, ncols_h, hq, L.dgates, hq,
-                         [&](int n) { const int ci = n / 3, k = n - ci * 3; return St{hin_ + ci * hq, k - 1}; },
-                         [&](const St& st, int pp) { return st.row[wrapi(pp + st.off, hq)]; },
-                         [&](int m, int n, float v) {
-                             if (m < 4 * cs && n < ncols_h) {
-                                 const int gt = m / cs, o = m - gt * cs;
-                                 gh[gt * gate_stride + o * ncols_h + n] += v;
-                             }
-                         }, lo, hi);
-            };
-            gwh(w_gw, 0, th_split);
-            if (th_split < th_all) gwh(WaveSet{0, nwg / 2}, th_split, th_all);
-            STAMP(31);
-            float* gbx = g[SUR_ST_BXI];
-            for (int idx = threadIdx.x; idx < 4 * cs; idx += blockDim.x) {
-                const int gt = idx / cs, o = idx - gt * cs;
-                float a0 = 0.0f, a1 = 0.0f;
-                for (int pp = 0; pp < hq; pp += 2) {
-                    a0 += L.dgates[idx * hq + pp];
-                    a1 += L.dgates[idx * hq + pp + 1];
+        const float* wx = w[SUR_ST_WXI];
+        const GemmSeg sx[4] = {{wx, 3, ca * 3, L.dgates, hq, cs},
+                               {wx + gate_stride, 3, ca * 3, L.dgates + s, hq, cs},
+                               {wx + 2 * gate_stride, 3, ca * 3, L.dgates + 2 * s, hq, cs},
+                               {wx + 3 * gate_stride, 3, ca * 3, L.dgates + 3 * s, hq, cs}};
+        float* dxp = L.dx;
+        gemm_taps<3, 4>(w_dx, false, ca, hq, sx, tap_col, [&](int m, int j, float v) {
+            if (m < ca) dxp[m * hq + j] = v;
+        });
+    }
+    struct St { const float* row; int off; };
+    {   // weight gradients, all gates in one GEMM each: rows m = (gate, o)
+        float* gx = g[SUR_ST_WXI];
+        const float* xin = L.x;
+        const int ncols = ca * 3;
+        gemm_pos(w_gw, false, 4 * cs, ncols, hq, L.dgates, hq,
+                 [&](int n) { const int ci = n / 3, k = n - ci * 3; return St{xin + ci * hq, k - 1}; },
+                 [&](const St& st, int pp) { return st.row[wrapi(pp + st.off, hq)]; },
+                 [&](int m, int n, float v) {
+                     if (m < 4 * cs && n < ncols) {
+                         const int gt = m / cs, o = m - gt * cs;
+                         gx[gt * gate_stride + o * ncols + n] += v;
+                     }
+                 });
+        float* gh = g[SUR_ST_WHI];
+        const float* hin_ = L.h;
+        const int ncols_h = cs * 3;
+        gemm_pos(w_gw, false, 4 * cs, ncols_h, hq, L.dgates, hq,
+                 [&](int n) { const int ci = n / 3, k = n - ci * 3; return St{hin_ + ci * hq, k - 1}; },
+                 [&](const St& st, int pp) { return st.row[wrapi(pp + st.off, hq)]; },
+                 [&](int m, int n, float v) {
+                     if (m < 4 * cs && n < ncols_h) {
+                         const int gt = m / cs, o = m - gt * cs;
+                         gh[gt * gate_stride + o * ncols_h + n] += v;
+                     }
+                 });
+        // bias gradients: one 16-lane group per (gate, channel) row of dG
+        float* gbx = g[SUR_ST_BXI];
+        const int group = threadIdx.x >> 4, gl = threadIdx.x & 15, ngroups = blockDim.x >> 4;
+        for (int r0 = 0; r0 < 4 * cs; r0 += ngroups) {
+            const int r = r0 + group;
+            float a0 = 0.0f, a1 = 0.0f;
+            if (r < 4 * cs)
+                for (int pp = gl; pp < hq; pp += 32) {
+                    a0 += L.dgates[r * hq + pp];
+                    if (pp + 16 < hq) a1 += L.dgates[r * hq + pp + 16];
                 }
+            group_sum2(a0, a1, 16);
+            if (gl == 0 && r < 4 * cs) {
+                const int gt = r / cs, o = r - gt * cs;
                 gbx[gt * gate_stride + o] += a0 + a1;
             }
         }
-        __syncthreads();
     }
+    __syncthreads();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1132,8 +1129,11 @@ __host__ __device__ inline int cell_part_floats(const sur_chunk_params& p) { ret
 __host__ __device__ inline int dec_part_floats(const sur_chunk_params& p) { return step_block_floats(p) - cell_part_floats(p); }
 __host__ __device__ inline int cell_fwd_act_floats(const sur_chunk_params& p) { return p.ca * p.hq + 8 * p.cs * p.hq; }
 __host__ __device__ inline int cell_bwd_act_floats(const sur_chunk_params& p) {
-    const int s = p.cs * p.hq;   // x, h, c, [gates|cnew] twice (working copy + DMA target), dgates, dx, dhin, two carries
-    return p.ca * p.hq + 2 * s + 2 * 5 * s + 4 * s + p.ca * p.hq + s + 2 * s;
+    const int s = p.cs * p.hq;   // c, [gates|cnew] twice (working copy + DMA target), dgates, four dh partials, two carries
+    return s + 2 * 5 * s + 4 * s + 4 * s + 2 * s;
+}
+__host__ __device__ inline int cell_wgrad_act_floats(const sur_chunk_params& p) {
+    return 2 * p.ca * p.hq + 5 * p.cs * p.hq;   // x, dx, h_in, dgates
 }
 __host__ __device__ inline int dec_act_floats(const sur_chunk_params& p, bool backward) {
     const int s = p.cs * p.hq, n = 4 * p.hq;
@@ -1321,27 +1321,24 @@ dec_bwd_kernel(const sur_chunk_params p, const float* __restrict__ saved, const 
     if (grads_in_lds) add_to_row(row, gacc, psize_dec);
 }
 
-// BPTT through the cell chain of one sample: consumes dh_dec (decoder) and the upstream dh / dc gradients
+// BPTT through the cell chain of one sample: consumes dh_dec (decoder) and the upstream dh / dc gradients, emits the
+// gate gradients dG_k of every step (for cell_wgrad_kernel) and the gradient wrt the teacher-forced hidden inputs.
+// Only what is recurrent stays here: the gate derivative and dh_{k-1} = sum_g Wh_g^T dG_g.
 __global__ void __launch_bounds__(TPB)
-cell_bwd_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, const float* __restrict__ lstates_t,
-                const float* __restrict__ h0, const float* __restrict__ c0, const float* __restrict__ h_all,
-                const float* __restrict__ c_all, const float* __restrict__ saved, const float* __restrict__ dh_dec,
-                const float* __restrict__ dh_all, const float* __restrict__ dc_all, int K, int S, int B,
-                float* __restrict__ dxlat_t, float* __restrict__ dlstates_t, float* __restrict__ dh0, float* __restrict__ dc0,
-                int grads_in_lds, int row_base) {
+cell_bwd_kernel(const sur_chunk_params p, const float* __restrict__ c0, const float* __restrict__ c_all,
+                const float* __restrict__ saved, const float* __restrict__ dh_dec, const float* __restrict__ dh_all,
+                const float* __restrict__ dc_all, int K, int S, int B, float* __restrict__ dg_all,
+                float* __restrict__ dlstates_t, float* __restrict__ dh0, float* __restrict__ dc0) {
     extern __shared__ __align__(16) float lds[];
-    const int b = blockIdx.x, s = p.cs * p.hq, nx = p.ca * p.hq;
+    const int b = blockIdx.x, s = p.cs * p.hq;
     StepLayout L{};
-    L.x = lds;
-    L.h = L.x + nx;
-    L.c = L.h + s;
+    L.c = lds;
     L.gates = L.c + s;          // working copy of [gates | c_k]
     L.cnew = L.gates + 4 * s;
     float* next_blk = L.cnew + s;   // DMA target for the next step's [gates | c_k]
     L.dgates = next_blk + 5 * s;
-    L.dx = L.dgates + 4 * s;
-    L.dhin = L.dx + nx;
-    L.dh_carry = L.dhin + s;
+    float* part = L.dgates + 4 * s; // four partial dh tiles
+    L.dh_carry = part + 4 * s;
     L.dc_carry = L.dh_carry + s;
     float* wbase = L.dc_carry + s;
     const size_t save_stride = step_saved_floats(p);
@@ -1356,33 +1353,13 @@ cell_bwd_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, cons
     fetch_block(K - 1);
     const float* w[SUR_ST_NPARAM];
     stage_range<ST_NLSTM>(p, 0, wbase, w);
-    int psize_lstm = 0;
-    for (int i = 0; i < ST_NLSTM; ++i) psize_lstm += p.size[i];
-    int psize = psize_lstm;
-    for (int i = ST_NLSTM; i < SUR_ST_NPARAM; ++i) psize += p.size[i];
-    float* row = p.partial + (size_t)(row_base + b) * psize;
-    float* gacc = grads_in_lds ? wbase + psize_lstm : row;
-    float* g[SUR_ST_NPARAM];
-    {
-        int off = 0;
-        for (int i = 0; i < ST_NLSTM; ++i) {
-            g[i] = gacc + off;
-            off += p.size[i];
-        }
-        if (grads_in_lds)
-            for (int j = threadIdx.x; j < psize_lstm; j += blockDim.x) gacc[j] = 0.0f;
-    }
     for (int i = threadIdx.x; i < s; i += blockDim.x) L.dh_carry[i] = L.dc_carry[i] = 0.0f;
     __syncthreads();
 
     for (int k = K - 1; k >= 0; --k) {
         const size_t kb = (size_t)k * B + b;
-        for (int i = threadIdx.x; i < nx; i += blockDim.x) L.x[i] = xlat_t[kb * nx + i];
-        for (int i = threadIdx.x; i < s; i += blockDim.x) {
-            const size_t prev = ((size_t)(k - 1) * B + b) * s + i;
-            L.h[i] = (k < S) ? lstates_t[kb * s + i] : (k > 0 ? h_all[prev] : h0[(size_t)b * s + i]);
-            L.c[i] = (k > 0) ? c_all[prev] : c0[(size_t)b * s + i];
-        }
+        for (int i = threadIdx.x; i < s; i += blockDim.x)
+            L.c[i] = (k > 0) ? c_all[((size_t)(k - 1) * B + b) * s + i] : c0[(size_t)b * s + i];
         {   // the DMA of this step's [gates | c_k] was retired by the previous phase-closing barrier
             const float4* src = reinterpret_cast<const float4*>(next_blk);
             float4* dst = reinterpret_cast<float4*>(L.gates);
@@ -1394,19 +1371,24 @@ cell_bwd_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, cons
             const float gi = L.gates[i], gf = L.gates[s + i], gg = L.gates[2 * s + i], go = L.gates[3 * s + i];
             const float tc = tanhf(L.cnew[i]);
             const float dcn = L.dc_carry[i] + (dc_all ? dc_all[kb * s + i] : 0.0f) + dhn * go * (1.0f - tc * tc);
-            L.dgates[i] = dcn * gg * gi * (1.0f - gi);
-            L.dgates[s + i] = dcn * L.c[i] * gf * (1.0f - gf);
-            L.dgates[2 * s + i] = dcn * gi * (1.0f - gg * gg);
-            L.dgates[3 * s + i] = dhn * tc * go * (1.0f - go);
+            const float d0 = dcn * gg * gi * (1.0f - gi), d1 = dcn * L.c[i] * gf * (1.0f - gf),
+                        d2 = dcn * gi * (1.0f - gg * gg), d3 = dhn * tc * go * (1.0f - go);
+            L.dgates[i] = d0;
+            L.dgates[s + i] = d1;
+            L.dgates[2 * s + i] = d2;
+            L.dgates[3 * s + i] = d3;
+            float* dg = dg_all + kb * 4 * s;
+            dg[i] = d0;
+            dg[s + i] = d1;
+            dg[2 * s + i] = d2;
+            dg[3 * s + i] = d3;
             L.dc_carry[i] = dcn * gf;  // gradient wrt c_{k-1}
         }
         __syncthreads();
         if (k > 0) fetch_block(k - 1);
-        cell_backward_gemms(p, L, w, g);
-        if (dxlat_t)
-            for (int i = threadIdx.x; i < nx; i += blockDim.x) dxlat_t[kb * nx + i] = L.dx[i];
+        cell_dh_gemm(p, L, w, part);
         for (int i = threadIdx.x; i < s; i += blockDim.x) {
-            const float v_ = L.dhin[i];
+            const float v_ = (part[i] + part[s + i]) + (part[2 * s + i] + part[3 * s + i]);
             if (k < S) {  // h_in was the encoded given state: gradient goes to the state encoder
                 if (dlstates_t) dlstates_t[kb * s + i] = v_;
                 L.dh_carry[i] = 0.0f;
@@ -1420,10 +1402,53 @@ cell_bwd_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, cons
         if (dh0) dh0[(size_t)b * s + i] = L.dh_carry[i];  // non-zero only if step 0 was free running (S == 0)
         if (dc0) dc0[(size_t)b * s + i] = L.dc_carry[i];
     }
-    if (grads_in_lds) {
-        __syncthreads();
-        add_to_row(row, gacc, psize_lstm);
+}
+
+// Everything of the cell backward that is not recurrent, for all (step, sample) pairs in parallel: the gradient wrt
+// the latent action and the LSTM weight / bias gradients (into this workgroup's partial row).
+__global__ void __launch_bounds__(TPB, 2)
+cell_wgrad_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, const float* __restrict__ lstates_t,
+                  const float* __restrict__ h0, const float* __restrict__ h_all, const float* __restrict__ dg_all, int K, int S,
+                  int B, float* __restrict__ dxlat_t, int grads_in_lds, int row_base) {
+    extern __shared__ __align__(16) float lds[];
+    const int s = p.cs * p.hq, nx = p.ca * p.hq, M = K * B;
+    StepLayout L{};
+    L.x = lds;
+    L.dx = L.x + nx;
+    L.h = L.dx + nx;
+    L.dgates = L.h + s;
+    float* wbase = L.dgates + 4 * s;
+    const float* w[SUR_ST_NPARAM];
+    stage_range<ST_NLSTM>(p, 0, wbase, w);
+    int psize_lstm = 0;
+    for (int i = 0; i < ST_NLSTM; ++i) psize_lstm += p.size[i];
+    int psize = psize_lstm;
+    for (int i = ST_NLSTM; i < SUR_ST_NPARAM; ++i) psize += p.size[i];
+    float* row = p.partial + (size_t)(row_base + blockIdx.x) * psize;
+    float* gacc = grads_in_lds ? wbase + psize_lstm : row;
+    float* g[SUR_ST_NPARAM];
+    {
+        int off = 0;
+        for (int i = 0; i < ST_NLSTM; ++i) {
+            g[i] = gacc + off;
+            off += p.size[i];
+        }
+        if (grads_in_lds)
+            for (int j = threadIdx.x; j < psize_lstm; j += blockDim.x) gacc[j] = 0.0f;
     }
+    __syncthreads();
+    for (int m = blockIdx.x; m < M; m += gridDim.x) {
+        const int k = m / B, b = m - k * B;
+        const float* hin = (k < S) ? lstates_t + (size_t)m * s : (k > 0 ? h_all + ((size_t)(k - 1) * B + b) * s : h0 + (size_t)b * s);
+        for (int i = threadIdx.x; i < nx; i += blockDim.x) L.x[i] = xlat_t[(size_t)m * nx + i];
+        for (int i = threadIdx.x; i < s; i += blockDim.x) L.h[i] = hin[i];
+        lds_load_v4(L.dgates, dg_all + (size_t)m * 4 * s, s);
+        cell_wgrad_gemms(p, L, w, g);
+        if (dxlat_t)
+            for (int i = threadIdx.x; i < nx; i += blockDim.x) dxlat_t[(size_t)m * nx + i] = L.dx[i];
+        __syncthreads();
+    }
+    if (grads_in_lds) add_to_row(row, gacc, psize_lstm);
 }
 
 // g[i][j] += sum_r partial[r][off_i + j]; the partial rows are re-zeroed
@@ -1583,7 +1608,7 @@ int sur_chunk_forward(void* stream, const sur_chunk_params* p, const float* xlat
 
 int sur_chunk_workspace_floats(const sur_chunk_params* p, int k, int b) {
     if (!p || k <= 0 || b <= 0) return 0;
-    return k * b * (p->cs * p->hq + 4 * p->hq);   // dh_dec [K,B,cs,hq] + ga_all [K,B,1,N]
+    return k * b * (5 * p->cs * p->hq + 4 * p->hq);   // dh_dec [K,B,cs,hq] + dg_all [K,B,4,cs,hq] + ga_all [K,B,1,N]
 }
 
 int sur_chunk_backward(void* stream, const sur_chunk_params* p, const float* xlat_t, const float* lstates_t,
@@ -1606,7 +1631,8 @@ int sur_chunk_backward(void* stream, const sur_chunk_params* p, const float* xla
         for (int i = ST_NLSTM; i < SUR_ST_NPARAM; ++i) psize_dec += p->size[i];
         const int m = k * b, n = 4 * p->hq, sl = p->cs * p->hq;
         float* dh_dec = workspace;
-        float* ga_all = workspace + (size_t)m * sl;
+        float* dg_all = workspace + (size_t)m * sl;
+        float* ga_all = workspace + (size_t)m * 5 * sl;
         const float* ga = dd_all;
         if (dout_all || !dd_all) {
             if (int rc = launch_checked([&] {
@@ -1618,19 +1644,26 @@ int sur_chunk_backward(void* stream, const sur_chunk_params* p, const float* xla
         const size_t dec_base = sizeof(float) * (dec_act_floats(*p, true) + psize_dec);
         const int dec_gl = dec_base + sizeof(float) * psize_dec <= LDS_LIMIT ? 1 : 0;
         const size_t lds_dec = dec_base + (dec_gl ? sizeof(float) * psize_dec : 0);
-        const size_t cell_base = sizeof(float) * (cell_bwd_act_floats(*p) + psize_lstm);
-        const int cell_gl = cell_base + sizeof(float) * psize_lstm <= LDS_LIMIT ? 1 : 0;
-        const size_t lds_cell = cell_base + (cell_gl ? sizeof(float) * psize_lstm : 0);
+        const size_t lds_cell = sizeof(float) * (cell_bwd_act_floats(*p) + psize_lstm);
+        const size_t wg_base = sizeof(float) * (cell_wgrad_act_floats(*p) + psize_lstm);
+        const int wg_gl = wg_base + sizeof(float) * psize_lstm <= LDS_LIMIT ? 1 : 0;
+        const size_t lds_wg = wg_base + (wg_gl ? sizeof(float) * psize_lstm : 0);
         if (int rc = set_lds(dec_bwd_kernel, lds_dec, "decoder backward")) return rc;
         if (int rc = set_lds(cell_bwd_kernel, lds_cell, "cell backward")) return rc;
+        if (int rc = set_lds(cell_wgrad_kernel, lds_wg, "cell weight gradients")) return rc;
+        const int grid = m < row_count ? m : row_count;
         if (int rc = launch_checked([&] {
-                hipLaunchKernelGGL(dec_bwd_kernel, dim3(m < row_count ? m : row_count), dim3(TPB), lds_dec, (hipStream_t)stream, *p,
-                                   saved, ga, m, dh_dec, dec_gl, row_base);
+                hipLaunchKernelGGL(dec_bwd_kernel, dim3(grid), dim3(TPB), lds_dec, (hipStream_t)stream, *p, saved, ga, m, dh_dec,
+                                   dec_gl, row_base);
             }, "dec_bwd")) return rc;
+        if (int rc = launch_checked([&] {
+                hipLaunchKernelGGL(cell_bwd_kernel, dim3(b), dim3(TPB), lds_cell, (hipStream_t)stream, *p, c0, c_all, saved, dh_dec,
+                                   dh_all, dc_all, k, s, b, dg_all, dlstates_t, dh0, dc0);
+            }, "cell_bwd")) return rc;
         return launch_checked([&] {
-            hipLaunchKernelGGL(cell_bwd_kernel, dim3(b), dim3(TPB), lds_cell, (hipStream_t)stream, *p, xlat_t, lstates_t, h0, c0,
-                               h_all, c_all, saved, dh_dec, dh_all, dc_all, k, s, b, dxlat_t, dlstates_t, dh0, dc0, cell_gl, row_base);
-        }, "cell_bwd");
+            hipLaunchKernelGGL(cell_wgrad_kernel, dim3(grid), dim3(TPB), lds_wg, (hipStream_t)stream, *p, xlat_t, lstates_t, h0,
+                               h_all, dg_all, k, s, b, dxlat_t, wg_gl, row_base);
+        }, "cell_wgrad");
     }
 }
 

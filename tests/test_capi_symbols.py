@@ -82,7 +82,7 @@ def test_surrogate_abi_rejects_bad_arguments_before_touching_the_device():
     for i, n in enumerate(sizes):
         chunk.size[i] = n
     assert lib.sur_chunk_saved_floats(ctypes.byref(chunk)) == 3840        # 3 712 floats padded to 1 KiB DMA pieces
-    assert lib.sur_chunk_workspace_floats(ctypes.byref(chunk), 10, 64) == 10 * 64 * (256 + 64)
+    assert lib.sur_chunk_workspace_floats(ctypes.byref(chunk), 10, 64) == 10 * 64 * (5 * 256 + 64)
     chunk.hq = 64                                                        # N = 256: one padded copy still fits
     assert lib.sur_chunk_saved_floats(ctypes.byref(chunk)) == 14848
     chunk.hq = 8                                                         # N = 32: latent rows narrower than a GEMM tile
