@@ -136,13 +136,15 @@ def run(device, steps=50, warmup=5, B=64, cpu_steps=3):
     # HBM model per step (N = 64, B = 64, T = 20): saved forward intermediates 3 840 floats per (step, sample) written
     # once and read once, hidden / cell states and deltas / outputs written once and read once, the batch read twice.
     t_len, n = 20, 64
-    bytes_model = 4 * B * t_len * (2 * 3840 + 2 * 2 * 256 + 2 * 2 * n + 2 * 2 * n)
+    # + the backward workspace (gate gradients 4 x 256, dh 256 per step and sample, written and read once)
+    bytes_model = 4 * B * t_len * (2 * 3840 + 2 * 2 * 256 + 2 * 2 * n + 2 * 2 * n + 2 * 5 * 256)
     ms = res["hip_graph_fused"]["ms_per_step"]
-    res["roofline"] = {"bound": "latency (dependent layer phases, one workgroup per sequence)", "kernels_per_step": 25,
+    res["roofline"] = {"bound": "latency (dependent layer phases, one workgroup per sequence)", "kernels_per_step": 33,
                        "reference_torch_ops_per_step": "~4 000", "hbm_model_bytes_per_step": bytes_model,
                        "hbm_model_gbs": bytes_model / (ms * 1e-3) / 1e9, "hbm_frac_of_8TBs": bytes_model / (ms * 1e-3) / 8e12,
-                       "critical_path": "enc_fwd -> chunk_fwd -> enc_fwd -> chunk_fwd -> loss -> chunk_bwd -> enc_bwd x2 -> "
-                                        "flush -> Adam (profiles/r01_tbptt_fused_v5_timeline.txt)"}
+                       "critical_path": "enc_fwd -> (cell chain -> decoders -> integrate) x2 with one encoder in between -> loss -> "
+                                        "decoder bwd -> cell chain bwd -> cell wgrad -> enc_bwd x2 -> flush -> Adam "
+                                        "(profiles/r01_tbptt_fused_v6_timeline.txt)"}
 
     # parity of the measured configuration: first-step loss GPU vs CPU (contract: 1e-5 relative)
     loss_gpu, loss_cpu = first_loss(device, B), first_loss("cpu", B)
