@@ -37,19 +37,15 @@ lib.sur_debug_stamps(None, 1)
 fwd_bwd()
 buf = (ctypes.c_longlong * 32)()
 lib.sur_debug_stamps(buf, 0)
-names = {1: "fwd gates gemm", 2: "fwd gate activations", 3: "fwd deconv0", 4: "fwd LN0+silu", 5: "fwd deconv1",
-         6: "fwd LN1+silu", 7: "fwd conv7", 8: "fwd LN2+silu", 9: "fwd conv5", 11: "fwd step output store",
-         12: "bwd dec: conv5 weight grad", 13: "bwd dec: conv5 data grad", 14: "bwd dec: LN2 bwd",
-         15: "bwd dec: conv7 weight grad", 16: "bwd dec: conv7 data grad", 17: "bwd dec: LN1 bwd",
-         18: "bwd dec: deconv1 weight grad", 19: "bwd dec: deconv1 data grad", 26: "bwd dec: LN0 bwd",
-         27: "bwd dec: deconv0 weight grad", 23: "bwd dec: deconv0 data grad",
-         28: "bwd cell: dx GEMM (alone)", 29: "bwd cell: dh GEMM (alone)", 30: "bwd cell: gWx GEMM (alone)",
-         31: "bwd cell: gWh GEMM (alone)", 25: "bwd cell: gate bias grads + closing barrier",
-         20: "bwd: load step inputs / commit prefetch", 21: "bwd: recompute forward or issue prefetch", 22: "bwd: dd assembly",
-         24: "bwd: cell elementwise"}
+names = {1: "cell fwd: gates GEMM", 2: "cell fwd: gate activations", 3: "dec fwd: deconv0", 4: "dec fwd: LN0+silu",
+         5: "dec fwd: deconv1", 6: "dec fwd: LN1+silu", 7: "dec fwd: conv7", 8: "dec fwd: LN2+silu", 9: "dec fwd: conv5",
+         12: "dec bwd: conv5 weight grad", 13: "dec bwd: conv5 data grad", 14: "dec bwd: LN2 bwd",
+         15: "dec bwd: conv7 weight grad", 16: "dec bwd: conv7 data grad", 17: "dec bwd: LN1 bwd",
+         18: "dec bwd: deconv1 weight grad", 19: "dec bwd: deconv1 data grad", 26: "dec bwd: LN0 bwd",
+         27: "dec bwd: deconv0 weight grad"}
 vals = list(buf)
-print("one training step (forward + backward), workgroup 0, shader-clock cycles per rollout step:")
-print("(with saved activations the backward kernel does not re-run phases 1-9: 20 executions each)")
+print("one training step (forward + backward), workgroup 0 of every launch, shader-clock cycles summed over the step:")
+print("(cell phases: 20 executions (2 chunks x 10 steps); decoder phases: the (step, sample) pairs workgroup 0 handles;")
+print(" the first phase of each kernel also contains the time since the previous stamped kernel ended)")
 for i, n in sorted(names.items()):
-    per = vals[i] / (20 if (i <= 9 or i >= 12) else 20)
-    print(f"  {n:55s} {per:9.0f}")
+    print(f"  {n:55s} {vals[i]:9d}")
