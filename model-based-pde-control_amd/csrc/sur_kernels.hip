@@ -1122,6 +1122,9 @@ __device__ void cell_wgrad_gemms(const sur_chunk_params& p, const StepLayout& L,
 // sample) carry only the cell.  Layout of a saved block (step_saved_floats per (step, sample)):
 //   [ gates 4s | c_k s | h_k s | p0 | a0 | p1 | a1 | p2 | a2 ]     cell part = first 6s floats
 // ---------------------------------------------------------------------------------------------
+#ifndef PAR_OCC
+#define PAR_OCC 2   // resident workgroups per CU the (step, sample)-parallel kernels are built for
+#endif
 constexpr int ST_NLSTM = SUR_ST_DC0_W;              // the LSTM parameters come first in the chunk parameter order
 constexpr int ST_NDEC = SUR_ST_NPARAM - ST_NLSTM;
 
@@ -1206,7 +1209,7 @@ cell_fwd_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, cons
 }
 
 // decoder of every (step, sample) pair m: d_all[m] from h_all[m]; persistent workgroups
-__global__ void __launch_bounds__(TPB, 2)
+__global__ void __launch_bounds__(TPB, PAR_OCC)
 dec_fwd_kernel(const sur_chunk_params p, const float* __restrict__ h_all, int M, float* __restrict__ d_all,
                float* __restrict__ saved) {
     extern __shared__ __align__(16) float lds[];
@@ -1270,7 +1273,7 @@ dgrad_scan_kernel(const float* __restrict__ dd_all, const float* __restrict__ do
 
 // decoder backward of every (step, sample) pair: dh_dec[m] = d loss / d h_m through the decoder; decoder parameter
 // gradients into this workgroup's partial row.  Built for two workgroups per CU.
-__global__ void __launch_bounds__(TPB, 2)
+__global__ void __launch_bounds__(TPB, PAR_OCC)
 dec_bwd_kernel(const sur_chunk_params p, const float* __restrict__ saved, const float* __restrict__ ga_all, int M,
                float* __restrict__ dh_dec, int grads_in_lds, int row_base) {
     extern __shared__ __align__(16) float lds[];
@@ -1406,7 +1409,7 @@ cell_bwd_kernel(const sur_chunk_params p, const float* __restrict__ c0, const fl
 
 // Everything of the cell backward that is not recurrent, for all (step, sample) pairs in parallel: the gradient wrt
 // the latent action and the LSTM weight / bias gradients (into this workgroup's partial row).
-__global__ void __launch_bounds__(TPB, 2)
+__global__ void __launch_bounds__(TPB, PAR_OCC)
 cell_wgrad_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, const float* __restrict__ lstates_t,
                   const float* __restrict__ h0, const float* __restrict__ h_all, const float* __restrict__ dg_all, int K, int S,
                   int B, float* __restrict__ dxlat_t, int grads_in_lds, int row_base) {
@@ -1460,10 +1463,22 @@ __global__ void __launch_bounds__(TPB) flush_grads_kernel(const Params p, int ps
     const int t = blockIdx.x * 32 + col;
     float acc = 0.0f;
     if (t < psize) {
-        for (int r = rg; r < p.rows; r += 8) {
-            float* q = p.partial + (size_t)r * psize + t;
-            acc += *q;
-            *q = 0.0f;
+        constexpr int U = 8;   // loads of a round all in flight before the first add / re-zero (same summation order)
+        for (int r0 = rg; r0 < p.rows; r0 += 8 * U) {
+            float v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int r = r0 + 8 * u;
+                v[u] = r < p.rows ? p.partial[(size_t)r * psize + t] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int r = r0 + 8 * u;
+                if (r < p.rows) {
+                    acc += v[u];
+                    p.partial[(size_t)r * psize + t] = 0.0f;
+                }
+            }
         }
     }
     part[rg][col] = acc;

@@ -134,7 +134,7 @@ class _Pack:
 # SIMD) hide each other's dependent-phase latency
 ENCODER_ROWS = 512
 # partial rows of one chunk backward launch: the parallel decoder backward runs one workgroup per row
-CHUNK_ROWS = 256
+CHUNK_ROWS = 384
 
 
 def _encoder_pack(convnet, n):
