@@ -98,10 +98,12 @@ int sur_chunk_workspace_floats(const sur_chunk_params* p, int k, int b);
  * `saved` and `workspace`) runs the decoder backward of all pairs in parallel, then the cell chain's BPTT.
  *
  * Time-major tensors: xlat_t [K,B,ca,hq]; lstates_t [S,B,cs,hq] (encoded given states, S >= 1);
- * states_t [S,B,1,N] (the given states: bases of the teacher-forced steps); h0, c0 [B,cs,hq].
+ * states_t [S,B,1,N] (the given states: bases of the teacher-forced steps); h0, c0 [B,cs,hq] with hc_bstride =
+ * cs*hq elements between samples, or ONE [cs,hq] initial state shared by the batch with hc_bstride = 0 (the
+ * reference's H0 / C0 parameters, transition.py:254-259).
  * Outputs: h_all, c_all [K,B,cs,hq]; d_all, out_all [K,B,1,N]. */
 int sur_chunk_forward(void* stream, const sur_chunk_params* p, const float* xlat_t, const float* lstates_t,
-                      const float* states_t, const float* h0, const float* c0, int k, int s, int b, float* h_all,
+                      const float* states_t, const float* h0, const float* c0, int hc_bstride, int k, int s, int b, float* h_all,
                       float* c_all, float* d_all, float* out_all, float* saved /* NULL: forward only, no backward later */);
 /* Upstream gradients (each may be NULL = 0): dd_all / dout_all [K,B,1,N] wrt d_all / out_all;
  * dh_all / dc_all [K,B,cs,hq] wrt h_all / c_all.  Outputs (each may be NULL): dxlat_t [K,B,ca,hq],
@@ -109,7 +111,7 @@ int sur_chunk_forward(void* stream, const sur_chunk_params* p, const float* xlat
  * [row_base, row_base + row_count) of p->partial (row_count >= B; the parallel decoder backward uses one row
  * per workgroup, up to row_count of them). */
 int sur_chunk_backward(void* stream, const sur_chunk_params* p, const float* xlat_t, const float* lstates_t,
-                       const float* h0, const float* c0, const float* h_all, const float* c_all,
+                       const float* h0, const float* c0, int hc_bstride, const float* h_all, const float* c_all,
                        const float* dd_all, const float* dout_all, const float* dh_all, const float* dc_all, int k,
                        int s, int b, float* dxlat_t, float* dlstates_t, float* dh0, float* dc0, int row_base, int row_count,
                        const float* saved /* what sur_chunk_forward wrote */, float* workspace /* sur_chunk_workspace_floats */);

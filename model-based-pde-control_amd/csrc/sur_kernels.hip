@@ -1155,8 +1155,8 @@ __device__ __forceinline__ void stage_range(const sur_chunk_params& p, int first
 
 __global__ void __launch_bounds__(TPB)
 cell_fwd_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, const float* __restrict__ lstates_t,
-                const float* __restrict__ h0, const float* __restrict__ c0, int K, int S, int B, float* __restrict__ h_all,
-                float* __restrict__ c_all, float* __restrict__ saved) {
+                const float* __restrict__ h0, const float* __restrict__ c0, int hc_bstride, int K, int S, int B,
+                float* __restrict__ h_all, float* __restrict__ c_all, float* __restrict__ saved) {
     extern __shared__ __align__(16) float lds[];
     const int b = blockIdx.x, s = p.cs * p.hq, nx = p.ca * p.hq;
     StepLayout L{};
@@ -1170,8 +1170,8 @@ cell_fwd_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, cons
     stage_range<ST_NLSTM>(p, 0, L.hnew + s, w);
     const size_t save_stride = step_saved_floats(p);
     for (int i = threadIdx.x; i < s; i += blockDim.x) {
-        L.hnew[i] = h0[(size_t)b * s + i];
-        L.cnew[i] = c0[(size_t)b * s + i];
+        L.hnew[i] = h0[(size_t)b * hc_bstride + i];   // hc_bstride = 0: one initial state shared by the batch
+        L.cnew[i] = c0[(size_t)b * hc_bstride + i];
     }
     // the next step's latent action is fetched while this step computes
     float xn[4];
@@ -1328,7 +1328,7 @@ dec_bwd_kernel(const sur_chunk_params p, const float* __restrict__ saved, const 
 // gate gradients dG_k of every step (for cell_wgrad_kernel) and the gradient wrt the teacher-forced hidden inputs.
 // Only what is recurrent stays here: the gate derivative and dh_{k-1} = sum_g Wh_g^T dG_g.
 __global__ void __launch_bounds__(TPB)
-cell_bwd_kernel(const sur_chunk_params p, const float* __restrict__ c0, const float* __restrict__ c_all,
+cell_bwd_kernel(const sur_chunk_params p, const float* __restrict__ c0, int hc_bstride, const float* __restrict__ c_all,
                 const float* __restrict__ saved, const float* __restrict__ dh_dec, const float* __restrict__ dh_all,
                 const float* __restrict__ dc_all, int K, int S, int B, float* __restrict__ dg_all,
                 float* __restrict__ dlstates_t, float* __restrict__ dh0, float* __restrict__ dc0) {
@@ -1362,7 +1362,7 @@ cell_bwd_kernel(const sur_chunk_params p, const float* __restrict__ c0, const fl
     for (int k = K - 1; k >= 0; --k) {
         const size_t kb = (size_t)k * B + b;
         for (int i = threadIdx.x; i < s; i += blockDim.x)
-            L.c[i] = (k > 0) ? c_all[((size_t)(k - 1) * B + b) * s + i] : c0[(size_t)b * s + i];
+            L.c[i] = (k > 0) ? c_all[((size_t)(k - 1) * B + b) * s + i] : c0[(size_t)b * hc_bstride + i];
         {   // the DMA of this step's [gates | c_k] was retired by the previous phase-closing barrier
             const float4* src = reinterpret_cast<const float4*>(next_blk);
             float4* dst = reinterpret_cast<float4*>(L.gates);
@@ -1411,8 +1411,9 @@ cell_bwd_kernel(const sur_chunk_params p, const float* __restrict__ c0, const fl
 // the latent action and the LSTM weight / bias gradients (into this workgroup's partial row).
 __global__ void __launch_bounds__(TPB, PAR_OCC)
 cell_wgrad_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, const float* __restrict__ lstates_t,
-                  const float* __restrict__ h0, const float* __restrict__ h_all, const float* __restrict__ dg_all, int K, int S,
-                  int B, float* __restrict__ dxlat_t, int grads_in_lds, int row_base) {
+                  const float* __restrict__ h0, int hc_bstride, const float* __restrict__ h_all,
+                  const float* __restrict__ dg_all, int K, int S, int B, float* __restrict__ dxlat_t, int grads_in_lds,
+                  int row_base) {
     extern __shared__ __align__(16) float lds[];
     const int s = p.cs * p.hq, nx = p.ca * p.hq, M = K * B;
     StepLayout L{};
@@ -1442,7 +1443,7 @@ cell_wgrad_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, co
     __syncthreads();
     for (int m = blockIdx.x; m < M; m += gridDim.x) {
         const int k = m / B, b = m - k * B;
-        const float* hin = (k < S) ? lstates_t + (size_t)m * s : (k > 0 ? h_all + ((size_t)(k - 1) * B + b) * s : h0 + (size_t)b * s);
+        const float* hin = (k < S) ? lstates_t + (size_t)m * s : (k > 0 ? h_all + ((size_t)(k - 1) * B + b) * s : h0 + (size_t)b * hc_bstride);
         for (int i = threadIdx.x; i < nx; i += blockDim.x) L.x[i] = xlat_t[(size_t)m * nx + i];
         for (int i = threadIdx.x; i < s; i += blockDim.x) L.h[i] = hin[i];
         lds_load_v4(L.dgates, dg_all + (size_t)m * 4 * s, s);
@@ -1588,10 +1589,10 @@ int sur_chunk_saved_floats(const sur_chunk_params* p) {
 }
 
 int sur_chunk_forward(void* stream, const sur_chunk_params* p, const float* xlat_t, const float* lstates_t,
-                      const float* states_t, const float* h0, const float* c0, int k, int s, int b, float* h_all,
-                      float* c_all, float* d_all, float* out_all, float* saved) {
+                      const float* states_t, const float* h0, const float* c0, int hc_bstride, int k, int s, int b,
+                      float* h_all, float* c_all, float* d_all, float* out_all, float* saved) {
     if (!p || !xlat_t || !h0 || !c0 || !h_all || !c_all || !d_all || !out_all || k <= 0 || b <= 0 || s < 1 ||
-        !lstates_t || !states_t)
+        !lstates_t || !states_t || hc_bstride < 0)
         return fail(-1, "sur_chunk_forward: bad argument (need K > 0, B > 0, S >= 1)");
     if (4 * p->hq > 64 * LN_MAX_EPL) return fail(-4, "sur_chunk_forward: N = %d too wide for the fused LayerNorm", 4 * p->hq);
     if (p->hq & 15) return fail(-4, "sur_chunk_forward: latent width N/4 = %d must be a multiple of 16", p->hq);
@@ -1608,8 +1609,8 @@ int sur_chunk_forward(void* stream, const sur_chunk_params* p, const float* xlat
     if (int rc = set_lds(dec_fwd_kernel, lds_dec, "decoder forward")) return rc;
     const int m = k * b, n = 4 * p->hq;
     if (int rc = launch_checked([&] {
-            hipLaunchKernelGGL(cell_fwd_kernel, dim3(b), dim3(TPB), lds_cell, (hipStream_t)stream, *p, xlat_t, lstates_t, h0, c0, k,
-                               s, b, h_all, c_all, saved);
+            hipLaunchKernelGGL(cell_fwd_kernel, dim3(b), dim3(TPB), lds_cell, (hipStream_t)stream, *p, xlat_t, lstates_t, h0, c0,
+                               hc_bstride, k, s, b, h_all, c_all, saved);
         }, "cell_fwd")) return rc;
     if (int rc = launch_checked([&] {
             hipLaunchKernelGGL(dec_fwd_kernel, dim3(m < 1024 ? m : 1024), dim3(TPB), lds_dec, (hipStream_t)stream, *p, h_all, m,
@@ -1627,7 +1628,8 @@ int sur_chunk_workspace_floats(const sur_chunk_params* p, int k, int b) {
 }
 
 int sur_chunk_backward(void* stream, const sur_chunk_params* p, const float* xlat_t, const float* lstates_t,
-                       const float* h0, const float* c0, const float* h_all, const float* c_all, const float* dd_all,
+                       const float* h0, const float* c0, int hc_bstride, const float* h_all, const float* c_all,
+                       const float* dd_all,
                        const float* dout_all, const float* dh_all, const float* dc_all, int k, int s, int b,
                        float* dxlat_t, float* dlstates_t, float* dh0, float* dc0, int row_base, int row_count,
                        const float* saved, float* workspace) {
@@ -1672,12 +1674,13 @@ int sur_chunk_backward(void* stream, const sur_chunk_params* p, const float* xla
                                    dec_gl, row_base);
             }, "dec_bwd")) return rc;
         if (int rc = launch_checked([&] {
-                hipLaunchKernelGGL(cell_bwd_kernel, dim3(b), dim3(TPB), lds_cell, (hipStream_t)stream, *p, c0, c_all, saved, dh_dec,
+                hipLaunchKernelGGL(cell_bwd_kernel, dim3(b), dim3(TPB), lds_cell, (hipStream_t)stream, *p, c0, hc_bstride, c_all, saved,
+                                   dh_dec,
                                    dh_all, dc_all, k, s, b, dg_all, dlstates_t, dh0, dc0);
             }, "cell_bwd")) return rc;
         return launch_checked([&] {
             hipLaunchKernelGGL(cell_wgrad_kernel, dim3(grid), dim3(TPB), lds_wg, (hipStream_t)stream, *p, xlat_t, lstates_t, h0,
-                               h_all, dg_all, k, s, b, dxlat_t, wg_gl, row_base);
+                               hc_bstride, h_all, dg_all, k, s, b, dxlat_t, wg_gl, row_base);
         }, "cell_wgrad");
     }
 }

@@ -45,9 +45,9 @@ SYMBOLS = (
     ("sur_encoder_backward", [_fp, _EP, _fp, _fp, _i, _fp, _i, _i, _fp]),
     ("sur_flush_encoder_grads", [_fp, _EP]),
     ("sur_chunk_saved_floats", [_CP]),
-    ("sur_chunk_forward", [_fp, _CP, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _fp, _fp, _fp, _fp, _fp]),
+    ("sur_chunk_forward", [_fp, _CP, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _fp]),
     ("sur_chunk_workspace_floats", [_CP, _i, _i]),
-    ("sur_chunk_backward", [_fp, _CP, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _fp, _fp, _fp, _fp,
+    ("sur_chunk_backward", [_fp, _CP, _fp, _fp, _fp, _fp, _i, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _fp, _fp, _fp, _fp,
                             _i, _i, _fp, _fp]),
     ("sur_flush_chunk_grads", [_fp, _CP]),
     ("sur_tbptt_delta_loss", [_fp, _fp, _fp, _i, _i, _i, ctypes.c_float, ctypes.c_float, ctypes.c_float, _fp, _fp, _fp, _fp,
@@ -235,7 +235,6 @@ class FusedPacks:
         self._flush_queued = False
         self.side_streams = []
         self.loss_scratch = {}
-        self.h0c0 = None
 
     @staticmethod
     def _key(surrogate, n):
@@ -360,7 +359,8 @@ class _ChunkFn(torch.autograd.Function):
         out_all = torch.empty_like(d_all)
         saved = _saved_buffer(pack, k, b, xlat_t.device) if any(ctx.needs_input_grad) else None
         _check(load().sur_chunk_forward(_stream(), ctypes.byref(pack.c), _p(xlat_t), _p(lstates_t), _p(states_t), _p(h0),
-                                        _p(c0), k, s, b, _p(h_all), _p(c_all), _p(d_all), _p(out_all), _p(saved)))
+                                        _p(c0), pack.c.cs * pack.c.hq, k, s, b, _p(h_all), _p(c_all), _p(d_all), _p(out_all),
+                                        _p(saved)))
         ctx.save_for_backward(xlat_t, lstates_t, h0, c0, h_all, c_all)
         ctx.fwd_saved = saved
         ctx.pack, ctx.owner = pack, owner
@@ -384,7 +384,7 @@ class _ChunkFn(torch.autograd.Function):
         ctx.owner.refresh_partials()
         work = _chunk_workspace(ctx.pack, k, b, xlat_t.device) if ctx.fwd_saved is not None else None
         _check(load().sur_chunk_backward(_stream(), ctypes.byref(ctx.pack.c), _p(xlat_t), _p(lstates_t), _p(h0), _p(c0),
-                                         _p(h_all), _p(c_all), _p(dd_all), _p(dout_all), _p(dh_all), _p(dc_all), k,
+                                         ctx.pack.c.cs * ctx.pack.c.hq, _p(h_all), _p(c_all), _p(dd_all), _p(dout_all), _p(dh_all), _p(dc_all), k,
                                          lstates_t.shape[0], b, _p(dxlat), _p(dlst), _p(dh0), _p(dc0), 0, rows,
                                          _p(ctx.fwd_saved), _p(work)))
         ctx.fwd_saved = None
@@ -548,27 +548,36 @@ class _TBPTTFn(torch.autograd.Function):
         actions_t = actions.transpose(0, 1).contiguous()                    # [T, B, 1, N]
         states_t0 = states[:, :tau].transpose(0, 1).contiguous()            # [tau, B, 1, N]
         lactions_t = torch.empty((t_total, b, ca, hq), device=dev, dtype=torch.float32)
+        # Action latents chunk by chunk on the side stream: chunk 0's first (the cell chain waits for them, beside the
+        # chunk-0 state encoding), the later chunks' while chunk 0's cell chain occupies only B of the 256 CUs.
+        asaved = _encoder_saved_buffer(owner.action_enc, t_total * b, dev)
+        af = 0 if asaved is None else asaved.shape[1]
+        nin, nlat = actions_t.shape[2] * n, ca * hq
         fork = _Fork(side)
-        with fork:   # all T action encodings in one launch, beside the chunk-0 state encoding
-            asaved = _encoder_saved_buffer(owner.action_enc, t_total * b, dev)
-            _check(lib.sur_encoder_forward(_stream(), ctypes.byref(owner.action_enc.c), _p(actions_t), t_total * b,
-                                           _p(lactions_t), _p(asaved)))
-            if asaved is not None:
-                asaved.record_stream(torch.cuda.current_stream(dev))
+        lat_ready = []
+        with fork:
+            for (k0, k1) in bounds:
+                lo, m = k0 * b, (k1 - k0) * b
+                sv = None if asaved is None else ctypes.c_void_p(asaved.data_ptr() + 4 * lo * af)
+                _check(lib.sur_encoder_forward(_stream(), ctypes.byref(owner.action_enc.c),
+                                               ctypes.c_void_p(actions_t.data_ptr() + 4 * lo * nin), m,
+                                               ctypes.c_void_p(lactions_t.data_ptr() + 4 * lo * nlat), sv))
+                if fork.forked:
+                    ev = torch.cuda.Event()
+                    ev.record(fork.stream)
+                    lat_ready.append(ev)
+            for t in (asaved, lactions_t, actions_t):
+                if t is not None:
+                    t.record_stream(torch.cuda.current_stream(dev))
         lstates = [torch.empty((tau, b, cs, hq), device=dev, dtype=torch.float32)]
         ssaved = [_encoder_saved_buffer(owner.state_enc, tau * b, dev)]
         _check(lib.sur_encoder_forward(_stream(), ctypes.byref(owner.state_enc.c), _p(states_t0), tau * b, _p(lstates[0]),
                                        _p(ssaved[0])))
-        fork.join()
+        main = torch.cuda.current_stream(dev)
 
         tm = surrogate.transition_model
-        # batch-expanded initial hidden / cell state: constant between optimizer steps (H0 / C0 are not trained),
-        # so the two expand kernels run once per (batch size, parameter version), not once per step
-        key = (b, tm.H0.data_ptr(), tm.H0._version, tm.C0.data_ptr(), tm.C0._version)
-        if owner.h0c0 is None or owner.h0c0[0] != key:
-            owner.h0c0 = (key, tm.H0.detach().unsqueeze(0).expand(b, -1, -1).contiguous(),
-                          tm.C0.detach().unsqueeze(0).expand(b, -1, -1).contiguous())
-        _, h0, c0 = owner.h0c0
+        h0, c0 = tm.H0.detach().contiguous(), tm.C0.detach().contiguous()   # one [cs, hq] state shared by the batch
+        s_lat = cs * hq
         seeds, h0s, c0s, h_alls, c_alls, saveds = [states_t0], [h0], [c0], [], [], []
         d_all = torch.empty((t_total, b, 1, n), device=dev, dtype=torch.float32)
         out_all = torch.empty_like(d_all)
@@ -587,12 +596,15 @@ class _TBPTTFn(torch.autograd.Function):
             c_all = torch.empty_like(h_all)
             s_used = min(seeds[c].shape[0], k)
             saved = _saved_buffer(owner.chunk, k, b, dev)
+            if lat_ready:
+                main.wait_event(lat_ready[c])    # this chunk's action latents
             _check(lib.sur_chunk_forward(_stream(), ctypes.byref(owner.chunk.c), _p(lactions_t[k0:k1]), _p(lstates[c]),
-                                         _p(seeds[c]), _p(h0s[c]), _p(c0s[c]), k, s_used, b, _p(h_all), _p(c_all),
-                                         _p(d_all[k0:k1]), _p(out_all[k0:k1]), _p(saved)))
+                                         _p(seeds[c]), _p(h0s[c]), _p(c0s[c]), 0 if c == 0 else s_lat, k, s_used, b,
+                                         _p(h_all), _p(c_all), _p(d_all[k0:k1]), _p(out_all[k0:k1]), _p(saved)))
             h_alls.append(h_all)
             c_alls.append(c_all)
             saveds.append(saved)
+        fork.join()
         ctx.owner, ctx.bounds, ctx.dims = owner, bounds, (b, t_total, n, nchunks)
         ctx.saved = (actions_t, lactions_t, seeds, lstates, h0s, c0s, h_alls, c_alls, saveds, asaved, ssaved)
         ctx.set_materialize_grads(False)
@@ -623,7 +635,8 @@ class _TBPTTFn(torch.autograd.Function):
                 dlst = torch.empty_like(lstates[c])
                 work = _chunk_workspace(owner.chunk, k1 - k0, b, dev) if saveds[c] is not None else None
                 _check(lib.sur_chunk_backward(_stream(), ctypes.byref(owner.chunk.c), _p(lactions_t[k0:k1]), _p(lstates[c]),
-                                              _p(h0s[c]), _p(c0s[c]), _p(h_alls[c]), _p(c_alls[c]), _p(dd_all[k0:k1]), None,
+                                              _p(h0s[c]), _p(c0s[c]), 0 if c == 0 else owner.chunk.c.cs * owner.chunk.c.hq,
+                                              _p(h_alls[c]), _p(c_alls[c]), _p(dd_all[k0:k1]), None,
                                               None, None, k1 - k0, min(seeds[c].shape[0], k1 - k0), b,
                                               _p(dxlat_all[k0:k1]), _p(dlst), None, None, c * rows, rows, _p(saveds[c]),
                                               _p(work)))

@@ -67,9 +67,9 @@ def test_surrogate_abi_rejects_bad_arguments_before_touching_the_device():
     assert lib.sur_encoder_forward(null, ctypes.byref(enc), null, 4, null, null) < 0
     assert b"sur_encoder_forward" in lib.sur_last_error()
     assert lib.sur_encoder_backward(null, ctypes.byref(enc), null, null, 4, null, 0, 1, null) < 0
-    assert lib.sur_chunk_forward(null, ctypes.byref(chunk), null, null, null, null, null, 0, 1, 1, null, null, null, null, null) < 0
+    assert lib.sur_chunk_forward(null, ctypes.byref(chunk), null, null, null, null, null, 0, 0, 1, 1, null, null, null, null, null) < 0
     assert b"sur_chunk_forward" in lib.sur_last_error()
-    assert lib.sur_chunk_backward(null, ctypes.byref(chunk), null, null, null, null, null, null, null, null, null, null, 1, 1,
+    assert lib.sur_chunk_backward(null, ctypes.byref(chunk), null, null, null, null, 0, null, null, null, null, null, null, 1, 1,
                                   1, null, null, null, null, 0, 1, null, null) < 0
     assert lib.sur_chunk_workspace_floats(ctypes.byref(chunk), 0, 4) == 0
     assert lib.sur_flush_encoder_grads(null, ctypes.byref(enc)) < 0      # no partial buffer
