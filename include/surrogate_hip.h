@@ -74,6 +74,20 @@ typedef struct sur_chunk_params {
  * geometry has no saved-activation path).  With `saved` [M, sur_encoder_saved_floats] the backward kernel loads
  * the three blocks' intermediates instead of recomputing them (a third of its time); results are bit-identical. */
 int sur_encoder_saved_floats(const sur_encoder_params* p);
+
+/* Optional optimizer step inside the flush launches: torch.optim.Adam(lr, betas, eps) without weight decay /
+ * amsgrad (reference: pdecontrol/surrogates/training.py:273-278).  m, v: flat [sum(size)] moment buffers in the
+ * pack's parameter order, zero-initialised; step: device counter of completed updates, incremented by the launch;
+ * ticket: one zero-initialised unsigned the launch leaves at zero.  With a descriptor the flush writes
+ * g = (sum of the partial rows) instead of accumulating into g, and updates the parameters in place. */
+typedef struct sur_adam {
+    float* m;
+    float* v;
+    int* step;
+    unsigned int* ticket;
+    float lr, beta1, beta2, eps;
+} sur_adam;
+
 int sur_encoder_forward(void* stream, const sur_encoder_params* p, const float* x, int m, float* z,
                         float* saved /* may be NULL */);
 /* dx may be NULL (raw data input).  Accumulates parameter gradients into rows
@@ -81,7 +95,7 @@ int sur_encoder_forward(void* stream, const sur_encoder_params* p, const float* 
  * concurrently on different streams must be given disjoint row ranges). */
 int sur_encoder_backward(void* stream, const sur_encoder_params* p, const float* x, const float* dz, int m,
                          float* dx, int row_base, int row_count, const float* saved /* or NULL = recompute */);
-int sur_flush_encoder_grads(void* stream, const sur_encoder_params* p);
+int sur_flush_encoder_grads(void* stream, const sur_encoder_params* p, const sur_adam* adam /* may be NULL */);
 
 /* Floats per (step, sample) of the forward intermediates sur_chunk_forward saves for sur_chunk_backward (activated
  * gates, c_k, h_k, decoder pre-/post-LayerNorm activations; 14.8 KB at N = 64), or 0 if the latent sizes are not
@@ -115,7 +129,7 @@ int sur_chunk_backward(void* stream, const sur_chunk_params* p, const float* xla
                        const float* dd_all, const float* dout_all, const float* dh_all, const float* dc_all, int k,
                        int s, int b, float* dxlat_t, float* dlstates_t, float* dh0, float* dc0, int row_base, int row_count,
                        const float* saved /* what sur_chunk_forward wrote */, float* workspace /* sur_chunk_workspace_floats */);
-int sur_flush_chunk_grads(void* stream, const sur_chunk_params* p);
+int sur_flush_chunk_grads(void* stream, const sur_chunk_params* p, const sur_adam* adam /* may be NULL */);
 
 /* Delta-mode TBPTT loss in one launch (reference: pdecontrol/surrogates/training.py:100-121):
  *   deltas[b,t]  = ((states[b,t+1] - states[b,t]) / delta - mean) / stdv          t < T-1   (undscaling forward)

@@ -1455,13 +1455,17 @@ cell_wgrad_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, co
     if (grads_in_lds) add_to_row(row, gacc, psize_lstm);
 }
 
-// g[i][j] += sum_r partial[r][off_i + j]; the partial rows are re-zeroed
+// g[i][j] += sum_r partial[r][off_i + j]; the partial rows are re-zeroed.  With an Adam descriptor the reduced gradient is
+// consumed on the spot: g = sum (not accumulated), then the torch.optim.Adam update of the parameter element
+// (no weight decay, no amsgrad; same formula as torch's fused kernel) -- the optimizer costs no extra launch and the
+// gradients need no zeroing pass.
 template <int NP, typename Params>
-__global__ void __launch_bounds__(TPB) flush_grads_kernel(const Params p, int psize) {
+__global__ void __launch_bounds__(TPB) flush_grads_kernel(const Params p, int psize, const sur_adam adam) {
     // block = 32 columns x 8 row groups: each thread sums every 8th row of its column, LDS combines the 8 partials
     __shared__ float part[8][33];
     const int col = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const int t = blockIdx.x * 32 + col;
+    const int step = adam.m ? *adam.step + 1 : 0;   // read before this block takes its ticket (see below)
     float acc = 0.0f;
     if (t < psize) {
         constexpr int U = 8;   // loads of a round all in flight before the first add / re-zero (same summation order)
@@ -1491,8 +1495,29 @@ __global__ void __launch_bounds__(TPB) flush_grads_kernel(const Params p, int ps
         int off = 0;
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
-            if (t >= off && t < off + p.size[i]) p.g[i][t - off] += tot;
+            if (t >= off && t < off + p.size[i]) {
+                if (adam.m) {
+                    p.g[i][t - off] = tot;
+                    const float m = adam.beta1 * adam.m[t] + (1.0f - adam.beta1) * tot;
+                    const float v = adam.beta2 * adam.v[t] + (1.0f - adam.beta2) * tot * tot;
+                    adam.m[t] = m;
+                    adam.v[t] = v;
+                    const float bc1 = 1.0f - powf(adam.beta1, (float)step), bc2 = 1.0f - powf(adam.beta2, (float)step);
+                    const float denom = sqrtf(v) / sqrtf(bc2) + adam.eps;
+                    float* w = const_cast<float*>(p.w[i]);
+                    w[t - off] -= (adam.lr / bc1) * (m / denom);
+                } else {
+                    p.g[i][t - off] += tot;
+                }
+            }
             off += p.size[i];
+        }
+    }
+    if (adam.m) {   // the workgroup that takes the last ticket has, like every other, already read the step count
+        __syncthreads();
+        if (threadIdx.x == 0 && atomicAdd(adam.ticket, 1u) == gridDim.x - 1) {
+            *adam.step = step;
+            *adam.ticket = 0u;
         }
     }
 }
@@ -1570,14 +1595,20 @@ int sur_encoder_backward(void* stream, const sur_encoder_params* p, const float*
     }, "enc_bwd");
 }
 
-int sur_flush_encoder_grads(void* stream, const sur_encoder_params* p) {
+int sur_flush_encoder_grads(void* stream, const sur_encoder_params* p, const sur_adam* adam) {
     if (!p || !p->partial) return fail(-1, "sur_flush_encoder_grads: bad argument");
     for (int i = 0; i < SUR_ENC_NPARAM; ++i)
         if (!p->g[i]) return fail(-1, "sur_flush_encoder_grads: gradient tensor %d is NULL", i);
     const int psize = psize_of<SUR_ENC_NPARAM>(p->size);
+    sur_adam ad{};
+    if (adam) {
+        if (!adam->m || !adam->v || !adam->step || !adam->ticket || !(adam->lr > 0.0f))
+            return fail(-1, "flush: incomplete Adam descriptor");
+        ad = *adam;
+    }
     return launch_checked([&] {
         hipLaunchKernelGGL((flush_grads_kernel<SUR_ENC_NPARAM, sur_encoder_params>), dim3((psize + 31) / 32), dim3(TPB), 0,
-                           (hipStream_t)stream, *p, psize);
+                           (hipStream_t)stream, *p, psize, ad);
     }, "flush_enc");
 }
 
@@ -1685,14 +1716,20 @@ int sur_chunk_backward(void* stream, const sur_chunk_params* p, const float* xla
     }
 }
 
-int sur_flush_chunk_grads(void* stream, const sur_chunk_params* p) {
+int sur_flush_chunk_grads(void* stream, const sur_chunk_params* p, const sur_adam* adam) {
     if (!p || !p->partial) return fail(-1, "sur_flush_chunk_grads: bad argument");
     for (int i = 0; i < SUR_ST_NPARAM; ++i)
         if (!p->g[i]) return fail(-1, "sur_flush_chunk_grads: gradient tensor %d is NULL", i);
     const int psize = psize_of<SUR_ST_NPARAM>(p->size);
+    sur_adam ad{};
+    if (adam) {
+        if (!adam->m || !adam->v || !adam->step || !adam->ticket || !(adam->lr > 0.0f))
+            return fail(-1, "flush: incomplete Adam descriptor");
+        ad = *adam;
+    }
     return launch_checked([&] {
         hipLaunchKernelGGL((flush_grads_kernel<SUR_ST_NPARAM, sur_chunk_params>), dim3((psize + 31) / 32), dim3(TPB), 0,
-                           (hipStream_t)stream, *p, psize);
+                           (hipStream_t)stream, *p, psize, ad);
     }, "flush_chunk");
 }
 

@@ -43,7 +43,8 @@ class EnsembleTBPTTStep:
                 for g, st in zip(self.members, [cur] + self.streams):
                     with torch.cuda.stream(st):
                         g.result = g._fwd_bwd()
-                        g.opt.step()
+                        if not g.adam_in_flush:
+                            g.opt.step()
                 for st in self.streams:
                     cur.wait_stream(st)                      # join
 

@@ -6,6 +6,8 @@ it is bound by launch latency, not by arithmetic.  MI355X-native answer: capture
 launch cost, no host synchronisation inside the step.
 
 Single GPU : [ zero grads | forward | backward | Adam ]                       = one graph
+             (on the fused kernels: [ forward | backward ] only -- the launches that reduce the partial
+             gradient rows apply the Adam update themselves, and nothing needs zeroing)
 Data parallel: [ zero | forward | backward ] -> all-reduce(flat bucket) -> [ Adam ]  = two graphs with one
              RCCL call between them (pdecontrol.surrogates.distributed.FlatGradBucket).
 """
@@ -31,6 +33,7 @@ class GraphedTBPTTStep:
         self.opt = self._make_adam()
         self.result = None
         self.g_main = self.g_opt = None
+        self.adam_in_flush = False
         self._prepare(warmup)
         if capture:
             self._capture()
@@ -44,7 +47,8 @@ class GraphedTBPTTStep:
             return torch.optim.Adam(params, lr=self.lr, capturable=True)
 
     def _fwd_bwd(self):
-        self.bucket.zero_()
+        if not self.adam_in_flush:
+            self.bucket.zero_()
         out = self.module.training_step((self.states, self.actions), 0)
         out["loss"].backward()
         return out
@@ -73,6 +77,13 @@ class GraphedTBPTTStep:
                 st["step"].zero_()
                 st["exp_avg"].zero_()
                 st["exp_avg_sq"].zero_()
+        # fused kernels, single GPU: the flush launches take the Adam step (fresh state, like self.opt's)
+        packs = getattr(self.module.surrogate, "_fused_packs", None)
+        from pdecontrol.surrogates import ops
+        if packs is not None and ops.fused_enabled() and not self.distributed:
+            betas, eps = self.opt.defaults["betas"], self.opt.defaults["eps"]
+            packs.enable_adam(self.lr, betas, eps)
+            self.adam_in_flush = True
         torch.cuda.synchronize(self.device)
 
     def _capture(self):
@@ -80,7 +91,8 @@ class GraphedTBPTTStep:
         if not self.distributed:
             with torch.cuda.graph(self.g_main):
                 self.result = self._fwd_bwd()
-                self.opt.step()
+                if not self.adam_in_flush:
+                    self.opt.step()
             self.g_opt = None
         else:
             with torch.cuda.graph(self.g_main):

@@ -38,18 +38,24 @@ class ChunkParams(ctypes.Structure):
                 ("rows", ctypes.c_int)]
 
 
+class AdamParams(ctypes.Structure):
+    _fields_ = [("m", _fp), ("v", _fp), ("step", _fp), ("ticket", _fp), ("lr", ctypes.c_float), ("beta1", ctypes.c_float),
+                ("beta2", ctypes.c_float), ("eps", ctypes.c_float)]
+
+
 _EP, _CP, _i = ctypes.POINTER(EncoderParams), ctypes.POINTER(ChunkParams), ctypes.c_int
+_AP = ctypes.POINTER(AdamParams)
 SYMBOLS = (
     ("sur_encoder_saved_floats", [_EP]),
     ("sur_encoder_forward", [_fp, _EP, _fp, _i, _fp, _fp]),
     ("sur_encoder_backward", [_fp, _EP, _fp, _fp, _i, _fp, _i, _i, _fp]),
-    ("sur_flush_encoder_grads", [_fp, _EP]),
+    ("sur_flush_encoder_grads", [_fp, _EP, _AP]),
     ("sur_chunk_saved_floats", [_CP]),
     ("sur_chunk_forward", [_fp, _CP, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _fp]),
     ("sur_chunk_workspace_floats", [_CP, _i, _i]),
     ("sur_chunk_backward", [_fp, _CP, _fp, _fp, _fp, _fp, _i, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _fp, _fp, _fp, _fp,
                             _i, _i, _fp, _fp]),
-    ("sur_flush_chunk_grads", [_fp, _CP]),
+    ("sur_flush_chunk_grads", [_fp, _CP, _AP]),
     ("sur_tbptt_delta_loss", [_fp, _fp, _fp, _i, _i, _i, ctypes.c_float, ctypes.c_float, ctypes.c_float, _fp, _fp, _fp, _fp,
                               _fp, _fp, _fp]),
 )
@@ -109,6 +115,7 @@ class _Pack:
         self.psize = sum(p.numel() for p in params)
         self.partial = None
         self.dirty = False
+        self.adam = None          # (AdamParams, tensors kept alive) when the optimizer step runs inside the flush
         self.ensure_rows(rows)
         self.refresh()
 
@@ -126,8 +133,21 @@ class _Pack:
 
     def flush(self):
         if self.dirty:
-            _check(self._flush_fn(_stream(), ctypes.byref(self.c)))
+            _check(self._flush_fn(_stream(), ctypes.byref(self.c), None if self.adam is None else ctypes.byref(self.adam[0])))
             self.dirty = False
+
+    def enable_adam(self, lr, betas=(0.9, 0.999), eps=1e-8):
+        """torch.optim.Adam(lr, betas, eps) applied by the flush launch itself (fresh moments, step 0)."""
+        dev = self.params[0].device
+        m = torch.zeros(self.psize, device=dev, dtype=torch.float32)
+        v = torch.zeros_like(m)
+        step = torch.zeros(1, device=dev, dtype=torch.int32)
+        ticket = torch.zeros(1, device=dev, dtype=torch.int32)
+        desc = AdamParams(m.data_ptr(), v.data_ptr(), step.data_ptr(), ticket.data_ptr(), lr, betas[0], betas[1], eps)
+        self.adam = (desc, m, v, step, ticket)
+
+    def disable_adam(self):
+        self.adam = None
 
 
 # one partial row per workgroup of the encoder backward: two workgroups per CU (the kernel is built for 2 waves per
@@ -272,6 +292,15 @@ class FusedPacks:
         dirty[0].flush()
         for fork in forks:
             fork.join()
+
+    def enable_adam(self, lr, betas=(0.9, 0.999), eps=1e-8):
+        """Every flush of these packs also takes the Adam step of its parameters (hipops._Pack.enable_adam)."""
+        for pack in self.packs:
+            pack.enable_adam(lr, betas, eps)
+
+    def disable_adam(self):
+        for pack in self.packs:
+            pack.disable_adam()
 
     def schedule_flush(self):
         """Called from inside a backward: run ``flush`` when the current backward pass finishes."""
