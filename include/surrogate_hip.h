@@ -95,6 +95,11 @@ int sur_encoder_forward(void* stream, const sur_encoder_params* p, const float* 
  * concurrently on different streams must be given disjoint row ranges). */
 int sur_encoder_backward(void* stream, const sur_encoder_params* p, const float* x, const float* dz, int m,
                          float* dx, int row_base, int row_count, const float* saved /* or NULL = recompute */);
+/* Up to three encoder backward jobs (arrays of length njobs; dx is not produced) in ONE launch: all workgroups are
+ * dispatched together, so the long action-encoder job does not queue behind the state-encoder jobs. */
+int sur_encoder_backward_multi(void* stream, int njobs, const sur_encoder_params* const* ps, const float* const* xs,
+                               const float* const* dzs, const int* ms, const int* row_bases, const int* row_counts,
+                               const float* const* saveds);
 int sur_flush_encoder_grads(void* stream, const sur_encoder_params* p, const sur_adam* adam /* may be NULL */);
 
 /* Floats per (step, sample) of the forward intermediates sur_chunk_forward saves for sur_chunk_backward (activated

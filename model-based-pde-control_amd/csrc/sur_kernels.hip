@@ -748,10 +748,10 @@ __global__ void __launch_bounds__(TPB) enc_fwd_kernel(const sur_encoder_params p
 #ifndef ENC_BWD_OCC
 #define ENC_BWD_OCC 2
 #endif
-__global__ void __launch_bounds__(TPB, ENC_BWD_OCC) enc_bwd_kernel(const sur_encoder_params p, const float* __restrict__ x,
-                                                      const float* __restrict__ dz, int m_total, float* __restrict__ dx,
-                                                      int grads_in_lds, int row_base, const float* __restrict__ saved) {
-    extern __shared__ __align__(16) float lds[];
+// body of the encoder backward for the workgroup `wg` of `nwg` working on one encoder (job)
+__device__ __forceinline__ void enc_bwd_body(const sur_encoder_params& p, const float* __restrict__ x,
+                                             const float* __restrict__ dz, int m_total, float* __restrict__ dx, int grads_in_lds,
+                                             int row_base, const float* __restrict__ saved, int wg, int nwg, float* lds) {
     STAMP(32);
     EncLayout L;
     enc_layout(p, lds, true, L);
@@ -759,12 +759,12 @@ __global__ void __launch_bounds__(TPB, ENC_BWD_OCC) enc_bwd_kernel(const sur_enc
     stage_weights<SUR_ENC_NPARAM>(p.w, p.size, L.end, v);
     STAMP(33);
     const int psize = psize_of<SUR_ENC_NPARAM>(p.size);
-    float* row = p.partial + (size_t)(row_base + blockIdx.x) * psize;
+    float* row = p.partial + (size_t)(row_base + wg) * psize;
     float* gacc = grads_in_lds ? L.end + psize : row;
     setup_grads<SUR_ENC_NPARAM>(p.size, gacc, grads_in_lds != 0, v);
     STAMP(34);
     const int nin = p.c[0] * p.n, nout = L.rb[2].cout * L.rb[2].hout;
-    for (int m = blockIdx.x; m < m_total; m += gridDim.x) {
+    for (int m = wg; m < m_total; m += nwg) {
         lds_load(L.rb[0].in, x + (size_t)m * nin, nin);
         STAMP(35);
         if (saved) {  // the second workgroup resident on this CU covers the load latency
@@ -793,6 +793,35 @@ __global__ void __launch_bounds__(TPB, ENC_BWD_OCC) enc_bwd_kernel(const sur_enc
         add_to_row(row, gacc, psize);
     }
     STAMP(42);
+}
+
+__global__ void __launch_bounds__(TPB, ENC_BWD_OCC) enc_bwd_kernel(const sur_encoder_params p, const float* __restrict__ x,
+                                                      const float* __restrict__ dz, int m_total, float* __restrict__ dx,
+                                                      int grads_in_lds, int row_base, const float* __restrict__ saved) {
+    extern __shared__ __align__(16) float lds[];
+    enc_bwd_body(p, x, dz, m_total, dx, grads_in_lds, row_base, saved, blockIdx.x, gridDim.x, lds);
+}
+
+// Several encoder backward jobs (different encoders / inputs) in ONE launch: the workgroups of all jobs are
+// dispatched together, so a long job never queues behind a short one on the same hardware queue.
+struct EncBwdJob {
+    sur_encoder_params p;
+    const float* x;
+    const float* dz;
+    const float* saved;
+    int m, row_base, wg_begin, wg_count, grads_in_lds;
+};
+
+__global__ void __launch_bounds__(TPB, ENC_BWD_OCC) enc_bwd_multi_kernel(const EncBwdJob j0, const EncBwdJob j1, const EncBwdJob j2,
+                                                                         int njobs) {
+    extern __shared__ __align__(16) float lds[];
+    const int wg = blockIdx.x;
+    if (njobs > 2 && wg >= j2.wg_begin)
+        enc_bwd_body(j2.p, j2.x, j2.dz, j2.m, nullptr, j2.grads_in_lds, j2.row_base, j2.saved, wg - j2.wg_begin, j2.wg_count, lds);
+    else if (njobs > 1 && wg >= j1.wg_begin)
+        enc_bwd_body(j1.p, j1.x, j1.dz, j1.m, nullptr, j1.grads_in_lds, j1.row_base, j1.saved, wg - j1.wg_begin, j1.wg_count, lds);
+    else
+        enc_bwd_body(j0.p, j0.x, j0.dz, j0.m, nullptr, j0.grads_in_lds, j0.row_base, j0.saved, wg, j0.wg_count, lds);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1593,6 +1622,37 @@ int sur_encoder_backward(void* stream, const sur_encoder_params* p, const float*
         hipLaunchKernelGGL(enc_bwd_kernel, dim3(grid), dim3(TPB), lds, (hipStream_t)stream, *p, x, dz, m, dx, grads_in_lds,
                            row_base, saved);
     }, "enc_bwd");
+}
+
+int sur_encoder_backward_multi(void* stream, int njobs, const sur_encoder_params* const* ps, const float* const* xs,
+                               const float* const* dzs, const int* ms, const int* row_bases, const int* row_counts,
+                               const float* const* saveds) {
+    if (njobs < 1 || njobs > 3 || !ps || !xs || !dzs || !ms || !row_bases || !row_counts || !saveds)
+        return fail(-1, "sur_encoder_backward_multi: bad argument (1 to 3 jobs)");
+    EncBwdJob jobs[3] = {};
+    size_t lds = 0;
+    int grid = 0;
+    for (int j = 0; j < njobs; ++j) {
+        const sur_encoder_params* p = ps[j];
+        if (!p || !xs[j] || !dzs[j] || ms[j] <= 0) return fail(-1, "sur_encoder_backward_multi: job %d: bad argument", j);
+        if (!p->partial || row_counts[j] <= 0 || row_bases[j] < 0 || row_bases[j] + row_counts[j] > p->rows)
+            return fail(-1, "sur_encoder_backward_multi: job %d: partial rows [%d, %d) outside the buffer of %d rows", j, row_bases[j],
+                        row_bases[j] + row_counts[j], p->rows);
+        if (saveds[j] && sur_encoder_saved_floats(p) == 0)
+            return fail(-4, "sur_encoder_backward_multi: job %d: this geometry has no saved-activation path", j);
+        const int psize = psize_of<SUR_ENC_NPARAM>(p->size);
+        const size_t base = sizeof(float) * (enc_act_floats(*p, true) + psize);
+        const int gl = (base + sizeof(float) * psize <= LDS_LIMIT) ? 1 : 0;
+        const size_t need = base + (gl ? sizeof(float) * psize : 0);
+        lds = need > lds ? need : lds;
+        const int wgs = ms[j] < row_counts[j] ? ms[j] : row_counts[j];
+        jobs[j] = EncBwdJob{*p, xs[j], dzs[j], saveds[j], ms[j], row_bases[j], grid, wgs, gl};
+        grid += wgs;
+    }
+    if (int rc = set_lds(enc_bwd_multi_kernel, lds, "encoder backward (multi)")) return rc;
+    return launch_checked([&] {
+        hipLaunchKernelGGL(enc_bwd_multi_kernel, dim3(grid), dim3(TPB), lds, (hipStream_t)stream, jobs[0], jobs[1], jobs[2], njobs);
+    }, "enc_bwd_multi");
 }
 
 int sur_flush_encoder_grads(void* stream, const sur_encoder_params* p, const sur_adam* adam) {

@@ -49,6 +49,8 @@ SYMBOLS = (
     ("sur_encoder_saved_floats", [_EP]),
     ("sur_encoder_forward", [_fp, _EP, _fp, _i, _fp, _fp]),
     ("sur_encoder_backward", [_fp, _EP, _fp, _fp, _i, _fp, _i, _i, _fp]),
+    ("sur_encoder_backward_multi", [_fp, _i, ctypes.POINTER(_EP), ctypes.POINTER(_fp), ctypes.POINTER(_fp),
+                                    ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_fp)]),
     ("sur_flush_encoder_grads", [_fp, _EP, _AP]),
     ("sur_chunk_saved_floats", [_CP]),
     ("sur_chunk_forward", [_fp, _CP, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _fp]),
@@ -461,6 +463,17 @@ def fused_delta_loss(surrogate, d_all, states, delta, mean, stdv):
     return _DeltaLossFn.apply(d_all, states, float(delta), float(mean), float(stdv), scratch)
 
 
+def _encoder_backward_multi(lib, jobs):
+    """jobs: up to three (pack, x, dz, m, row_base, row_count, saved) tuples -> one sur_encoder_backward_multi launch."""
+    n = len(jobs)
+    arr = lambda ctype, vals: (ctype * n)(*vals)
+    ptr = lambda t: ctypes.c_void_p(None if t is None else t.data_ptr())
+    _check(lib.sur_encoder_backward_multi(
+        _stream(), n, arr(_EP, [ctypes.pointer(j[0].c) for j in jobs]), arr(_fp, [ptr(j[1]) for j in jobs]),
+        arr(_fp, [ptr(j[2]) for j in jobs]), arr(_i, [j[3] for j in jobs]), arr(_i, [j[4] for j in jobs]),
+        arr(_i, [j[5] for j in jobs]), arr(_fp, [ptr(j[6]) for j in jobs])))
+
+
 def encode(x, pack, owner):
     """[M, C0, N] -> [M, C3, N/4] through the fused 3-block residual encoder."""
     return _EncoderFn.apply(x, owner.anchor, pack, owner)
@@ -657,7 +670,7 @@ class _TBPTTFn(torch.autograd.Function):
         owner.state_enc.ensure_rows(sum(enc_rows))
         owner.refresh_partials()
         streams = _side_streams(owner, dev, nchunks)
-        forks, chunk_done, row0 = [], [], 0
+        forks, dlsts = [], []
         for c, (k0, k1) in enumerate(bounds):
             fork = _Fork(streams[c])
             with fork:
@@ -669,27 +682,22 @@ class _TBPTTFn(torch.autograd.Function):
                                               None, None, k1 - k0, min(seeds[c].shape[0], k1 - k0), b,
                                               _p(dxlat_all[k0:k1]), _p(dlst), None, None, c * rows, rows, _p(saveds[c]),
                                               _p(work)))
-                if work is not None:
-                    work.record_stream(fork.stream)
-                if fork.forked:
-                    # the action-encoder backward below only needs the chunks' dxlat: it must not wait for the
-                    # state-encoder backward that follows on this side stream
-                    done = torch.cuda.Event()
-                    done.record(fork.stream)
-                    chunk_done.append(done)
-                m = lstates[c].shape[0] * b
-                _check(lib.sur_encoder_backward(_stream(), ctypes.byref(owner.state_enc.c), _p(seeds[c]), _p(dlst), m, None,
-                                                row0, enc_rows[c], _p(ssaved[c])))
-                dlst.record_stream(fork.stream)
-            row0 += enc_rows[c]
+                for t in (work, dlst):
+                    if t is not None:
+                        t.record_stream(fork.stream)
+            dlsts.append(dlst)
             forks.append(fork)
-        main = torch.cuda.current_stream(dev)
-        for done in chunk_done:
-            main.wait_event(done)
-        _check(lib.sur_encoder_backward(_stream(), ctypes.byref(owner.action_enc.c), _p(actions_t), _p(dxlat_all),
-                                        t_total * b, None, 0, min(ENCODER_ROWS, owner.action_enc.c.rows), _p(asaved)))
         for fork in forks:
             fork.join()
+        # every encoder backward of the step in launches of up to three jobs: all their workgroups are dispatched
+        # together (as separate launches the long action-encoder job queued behind a state-encoder job), longest first
+        jobs = [(owner.action_enc, actions_t, dxlat_all, t_total * b, 0, min(ENCODER_ROWS, owner.action_enc.c.rows), asaved)]
+        row0 = 0
+        for c in range(nchunks):
+            jobs.append((owner.state_enc, seeds[c], dlsts[c], lstates[c].shape[0] * b, row0, enc_rows[c], ssaved[c]))
+            row0 += enc_rows[c]
+        for j0 in range(0, len(jobs), 3):
+            _encoder_backward_multi(lib, jobs[j0:j0 + 3])
         for pack in owner.packs:
             pack.dirty = True
         owner.schedule_flush()
