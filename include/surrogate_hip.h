@@ -135,6 +135,9 @@ int sur_chunk_backward(void* stream, const sur_chunk_params* p, const float* xla
                        int s, int b, float* dxlat_t, float* dlstates_t, float* dh0, float* dc0, int row_base, int row_count,
                        const float* saved /* what sur_chunk_forward wrote */, float* workspace /* sur_chunk_workspace_floats */);
 int sur_flush_chunk_grads(void* stream, const sur_chunk_params* p, const sur_adam* adam /* may be NULL */);
+/* The reductions of a surrogate's three parameter packs (two encoders, chunk) in ONE launch. */
+int sur_flush_all_grads(void* stream, const sur_encoder_params* e0, const sur_adam* a0, const sur_encoder_params* e1,
+                        const sur_adam* a1, const sur_chunk_params* c2, const sur_adam* a2);
 
 /* Delta-mode TBPTT loss in one launch (reference: pdecontrol/surrogates/training.py:100-121):
  *   deltas[b,t]  = ((states[b,t+1] - states[b,t]) / delta - mean) / stdv          t < T-1   (undscaling forward)

@@ -1489,11 +1489,11 @@ cell_wgrad_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, co
 // (no weight decay, no amsgrad; same formula as torch's fused kernel) -- the optimizer costs no extra launch and the
 // gradients need no zeroing pass.
 template <int NP, typename Params>
-__global__ void __launch_bounds__(TPB) flush_grads_kernel(const Params p, int psize, const sur_adam adam) {
+__device__ __forceinline__ void flush_grads_body(const Params& p, int psize, const sur_adam& adam, int blk, int nblk) {
     // block = 32 columns x 8 row groups: each thread sums every 8th row of its column, LDS combines the 8 partials
     __shared__ float part[8][33];
     const int col = threadIdx.x & 31, rg = threadIdx.x >> 5;
-    const int t = blockIdx.x * 32 + col;
+    const int t = blk * 32 + col;
     const int step = adam.m ? *adam.step + 1 : 0;   // read before this block takes its ticket (see below)
     float acc = 0.0f;
     if (t < psize) {
@@ -1544,11 +1544,27 @@ __global__ void __launch_bounds__(TPB) flush_grads_kernel(const Params p, int ps
     }
     if (adam.m) {   // the workgroup that takes the last ticket has, like every other, already read the step count
         __syncthreads();
-        if (threadIdx.x == 0 && atomicAdd(adam.ticket, 1u) == gridDim.x - 1) {
+        if (threadIdx.x == 0 && atomicAdd(adam.ticket, 1u) == (unsigned)(nblk - 1)) {
             *adam.step = step;
             *adam.ticket = 0u;
         }
     }
+}
+
+template <int NP, typename Params>
+__global__ void __launch_bounds__(TPB) flush_grads_kernel(const Params p, int psize, const sur_adam adam) {
+    flush_grads_body<NP, Params>(p, psize, adam, blockIdx.x, gridDim.x);
+}
+
+// the three gradient reductions of a surrogate (state encoder, action encoder, chunk) in one launch
+__global__ void __launch_bounds__(TPB)
+flush_all_kernel(const sur_encoder_params e0, const sur_adam a0, int n0, const sur_encoder_params e1, const sur_adam a1, int n1,
+                 const sur_chunk_params c2, const sur_adam a2, int n2) {
+    const int b0 = (n0 + 31) / 32, b1 = (n1 + 31) / 32, b2 = (n2 + 31) / 32;
+    const int blk = blockIdx.x;
+    if (blk < b0) flush_grads_body<SUR_ENC_NPARAM, sur_encoder_params>(e0, n0, a0, blk, b0);
+    else if (blk < b0 + b1) flush_grads_body<SUR_ENC_NPARAM, sur_encoder_params>(e1, n1, a1, blk - b0, b1);
+    else flush_grads_body<SUR_ST_NPARAM, sur_chunk_params>(c2, n2, a2, blk - b0 - b1, b2);
 }
 
 template <typename F>
@@ -1791,6 +1807,29 @@ int sur_flush_chunk_grads(void* stream, const sur_chunk_params* p, const sur_ada
         hipLaunchKernelGGL((flush_grads_kernel<SUR_ST_NPARAM, sur_chunk_params>), dim3((psize + 31) / 32), dim3(TPB), 0,
                            (hipStream_t)stream, *p, psize, ad);
     }, "flush_chunk");
+}
+
+int sur_flush_all_grads(void* stream, const sur_encoder_params* e0, const sur_adam* a0, const sur_encoder_params* e1,
+                        const sur_adam* a1, const sur_chunk_params* c2, const sur_adam* a2) {
+    if (!e0 || !e1 || !c2 || !e0->partial || !e1->partial || !c2->partial) return fail(-1, "sur_flush_all_grads: bad argument");
+    for (int i = 0; i < SUR_ENC_NPARAM; ++i)
+        if (!e0->g[i] || !e1->g[i]) return fail(-1, "sur_flush_all_grads: encoder gradient tensor %d is NULL", i);
+    for (int i = 0; i < SUR_ST_NPARAM; ++i)
+        if (!c2->g[i]) return fail(-1, "sur_flush_all_grads: chunk gradient tensor %d is NULL", i);
+    const sur_adam* in[3] = {a0, a1, a2};
+    sur_adam ad[3] = {};
+    for (int j = 0; j < 3; ++j)
+        if (in[j]) {
+            if (!in[j]->m || !in[j]->v || !in[j]->step || !in[j]->ticket || !(in[j]->lr > 0.0f))
+                return fail(-1, "sur_flush_all_grads: incomplete Adam descriptor %d", j);
+            ad[j] = *in[j];
+        }
+    const int n0 = psize_of<SUR_ENC_NPARAM>(e0->size), n1 = psize_of<SUR_ENC_NPARAM>(e1->size), n2 = psize_of<SUR_ST_NPARAM>(c2->size);
+    const int grid = (n0 + 31) / 32 + (n1 + 31) / 32 + (n2 + 31) / 32;
+    return launch_checked([&] {
+        hipLaunchKernelGGL(flush_all_kernel, dim3(grid), dim3(TPB), 0, (hipStream_t)stream, *e0, ad[0], n0, *e1, ad[1], n1, *c2, ad[2],
+                           n2);
+    }, "flush_all");
 }
 
 int sur_tbptt_delta_loss(void* stream, const float* states, const float* d_all, int b, int t, int n, float delta, float mean,

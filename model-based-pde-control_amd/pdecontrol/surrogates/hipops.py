@@ -58,6 +58,7 @@ SYMBOLS = (
     ("sur_chunk_backward", [_fp, _CP, _fp, _fp, _fp, _fp, _i, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _fp, _fp, _fp, _fp,
                             _i, _i, _fp, _fp]),
     ("sur_flush_chunk_grads", [_fp, _CP, _AP]),
+    ("sur_flush_all_grads", [_fp, _EP, _AP, _EP, _AP, _CP, _AP]),
     ("sur_tbptt_delta_loss", [_fp, _fp, _fp, _i, _i, _i, ctypes.c_float, ctypes.c_float, ctypes.c_float, _fp, _fp, _fp, _fp,
                               _fp, _fp, _fp]),
 )
@@ -283,17 +284,16 @@ class FusedPacks:
         dirty = [pack for pack in self.packs if pack.dirty]
         if not dirty:
             return
-        # the reductions are independent: the first stays on the current stream, the others run beside it
-        dev = dirty[0].params[0].device
-        forks = []
-        for pack, stream in zip(dirty[1:], _side_streams(self, dev, len(dirty) - 1)):
-            fork = _Fork(stream)
-            with fork:
-                pack.flush()
-            forks.append(fork)
-        dirty[0].flush()
-        for fork in forks:
-            fork.join()
+        if len(dirty) == 3:   # the usual case: one launch reduces (and, with Adam enabled, applies) all three packs
+            ad = lambda pack: None if pack.adam is None else ctypes.byref(pack.adam[0])
+            _check(load().sur_flush_all_grads(_stream(), ctypes.byref(self.state_enc.c), ad(self.state_enc),
+                                              ctypes.byref(self.action_enc.c), ad(self.action_enc),
+                                              ctypes.byref(self.chunk.c), ad(self.chunk)))
+            for pack in dirty:
+                pack.dirty = False
+            return
+        for pack in dirty:
+            pack.flush()
 
     def enable_adam(self, lr, betas=(0.9, 0.999), eps=1e-8):
         """Every flush of these packs also takes the Adam step of its parameters (hipops._Pack.enable_adam)."""

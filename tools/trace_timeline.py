@@ -6,7 +6,7 @@ import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-is_flush = ["flush_grads_kernel" in r["Kernel_Name"] for r in rows]
+is_flush = [("flush_grads_kernel" in r["Kernel_Name"] or "flush_all_kernel" in r["Kernel_Name"]) for r in rows]
 starts = [i for i in range(1, len(rows)) if is_flush[i - 1] and not is_flush[i]]
 ends = [i for i in range(len(rows) - 1) if is_flush[i] and not is_flush[i + 1]] + ([len(rows) - 1] if is_flush[-1] else [])
 # the last complete step: from the last start that has a flush group after it
