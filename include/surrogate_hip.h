@@ -145,10 +145,12 @@ int sur_flush_all_grads(void* stream, const sur_encoder_params* e0, const sur_ad
  *   hsteploss[t] = the same mean per time step;  stats = {mean, unbiased std} of the predicted deltas
  *                  d_all[:T-1], then of the true deltas (the four "Train ... Delta" metrics)
  *   dd_all       = d loss / d d_all  [T,B,1,N] (last step zero), may be NULL
- * states [B,T,1,N]; d_all [T,B,1,N] time-major as written by sur_chunk_forward; deltas [B,T-1,1,N];
+ * states [B,T,1,N] with element strides (states_bstride, states_tstride) between samples / time steps -- contiguous
+ * batch-major (T*N, N) or a view of time-major storage (N, B*N); d_all [T,B,1,N] time-major as written by sur_chunk_forward; deltas [B,T-1,1,N];
  * hsteploss [T-1]; loss [1]; stats [4]; partial: scratch of 40*T doubles; ticket: one zero-initialised
  * unsigned the kernel leaves at zero.  Sums are fp64 and reduced in a fixed order (deterministic). */
-int sur_tbptt_delta_loss(void* stream, const float* states, const float* d_all, int b, int t, int n, float delta, float mean,
+int sur_tbptt_delta_loss(void* stream, const float* states, long states_bstride, long states_tstride, const float* d_all, int b,
+                         int t, int n, float delta, float mean,
                          float stdv, float* deltas, float* dd_all, float* hsteploss, float* loss, float* stats,
                          double* partial, unsigned int* ticket);
 

@@ -844,7 +844,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 __global__ void __launch_bounds__(TPB)
-delta_loss_kernel(const float* __restrict__ states, const float* __restrict__ d_all, int B, int T, int N, float delta,
+delta_loss_kernel(const float* __restrict__ states, long sb, long st, const float* __restrict__ d_all, int B, int T, int N, float delta,
                   float mean, float stdv, float* __restrict__ deltas, float* __restrict__ dd_all,
                   float* __restrict__ hsteploss, float* __restrict__ loss, float* __restrict__ stats,
                   double* __restrict__ partial, unsigned int* __restrict__ ticket) {
@@ -864,9 +864,9 @@ delta_loss_kernel(const float* __restrict__ states, const float* __restrict__ d_
             for (int u = 0; u < LOSS_UNROLL; ++u) {
                 const int e = e0 + u * stride, ec = e < per_t ? e : e0;
                 const int b = ec / N, i = ec - b * N;
-                const size_t sidx = ((size_t)b * T + t) * N + i;
+                const size_t sidx = (size_t)b * sb + (size_t)t * st + i;   // states[b, t] (any batch / time strides)
                 s0[u] = states[sidx];
-                s1[u] = states[sidx + N];
+                s1[u] = states[sidx + st];
                 od[u] = d_all[((size_t)t * B + b) * N + i];
             }
 #pragma unroll
@@ -1832,16 +1832,19 @@ int sur_flush_all_grads(void* stream, const sur_encoder_params* e0, const sur_ad
     }, "flush_all");
 }
 
-int sur_tbptt_delta_loss(void* stream, const float* states, const float* d_all, int b, int t, int n, float delta, float mean,
+int sur_tbptt_delta_loss(void* stream, const float* states, long states_bstride, long states_tstride, const float* d_all, int b,
+                         int t, int n, float delta, float mean,
                          float stdv, float* deltas, float* dd_all, float* hsteploss, float* loss, float* stats,
                          double* partial, unsigned int* ticket) {
     if (!states || !d_all || !deltas || !hsteploss || !loss || !stats || !partial || !ticket || b <= 0 || t < 2 || n <= 0)
         return fail(-1, "sur_tbptt_delta_loss: bad argument (need B > 0, T >= 2, N > 0)");
+    if (states_bstride < n || states_tstride < n) return fail(-1, "sur_tbptt_delta_loss: state strides must be at least N");
     if (!(delta != 0.0f) || !(stdv > 0.0f)) return fail(-1, "sur_tbptt_delta_loss: delta must be non-zero and std positive");
     int nsplit = (b * n + LOSS_UNROLL * TPB - 1) / (LOSS_UNROLL * TPB);
     nsplit = nsplit < 1 ? 1 : (nsplit > LOSS_MAX_SPLIT ? LOSS_MAX_SPLIT : nsplit);
     return launch_checked([&] {
-        hipLaunchKernelGGL(delta_loss_kernel, dim3(t, nsplit), dim3(TPB), 0, (hipStream_t)stream, states, d_all, b, t, n, delta, mean,
+        hipLaunchKernelGGL(delta_loss_kernel, dim3(t, nsplit), dim3(TPB), 0, (hipStream_t)stream, states, states_bstride,
+                           states_tstride, d_all, b, t, n, delta, mean,
                            stdv, deltas, dd_all, hsteploss, loss, stats, partial, ticket);
     }, "delta_loss");
 }

@@ -25,8 +25,11 @@ class GraphedTBPTTStep:
         dev = next(module.surrogate.parameters()).device
         assert dev.type == "cuda", "HIP graphs need the module on a GPU"
         self.device = dev
-        self.states = torch.zeros(batch_shape, device=dev)
-        self.actions = torch.zeros(action_shape or batch_shape, device=dev)
+        # static buffers: time-major storage behind the module's [B, T, 1, N] view, so that the time-major copies the
+        # fused path wants (hipops._TBPTTFn) are no-ops instead of two transposing kernels per step
+        tm = lambda shape: torch.zeros((shape[1], shape[0]) + tuple(shape[2:]), device=dev).transpose(0, 1)
+        self.states = tm(tuple(batch_shape))
+        self.actions = tm(tuple(action_shape or batch_shape))
         self.distributed = distributed
         self.bucket = FlatGradBucket(module.surrogate.parameters())
         self.lr = lr if lr is not None else module.lr

@@ -59,7 +59,7 @@ SYMBOLS = (
                             _i, _i, _fp, _fp]),
     ("sur_flush_chunk_grads", [_fp, _CP, _AP]),
     ("sur_flush_all_grads", [_fp, _EP, _AP, _EP, _AP, _CP, _AP]),
-    ("sur_tbptt_delta_loss", [_fp, _fp, _fp, _i, _i, _i, ctypes.c_float, ctypes.c_float, ctypes.c_float, _fp, _fp, _fp, _fp,
+    ("sur_tbptt_delta_loss", [_fp, _fp, ctypes.c_long, ctypes.c_long, _fp, _i, _i, _i, ctypes.c_float, ctypes.c_float, ctypes.c_float, _fp, _fp, _fp, _fp,
                               _fp, _fp, _fp]),
 )
 _lib = None
@@ -432,13 +432,16 @@ class _DeltaLossFn(torch.autograd.Function):
     def forward(ctx, d_all, states, delta, mean, stdv, scratch):
         t, b, _, n = d_all.shape
         dev = d_all.device
-        d_all, states = d_all.contiguous(), states.contiguous()
+        d_all = d_all.contiguous()
+        if states.stride(3) != 1:          # rows of N must be dense; batch / time strides are free (C = 1)
+            states = states.contiguous()
         new = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)
         deltas, hstep, loss, stats = new(b, t - 1, 1, n), new(t - 1), new(), new(4)
         dd = torch.empty_like(d_all) if ctx.needs_input_grad[0] else None
         ctx.set_materialize_grads(False)
         partial, ticket = scratch
-        _check(load().sur_tbptt_delta_loss(_stream(), _p(states), _p(d_all), b, t, n, delta, mean, stdv, _p(deltas), _p(dd),
+        _check(load().sur_tbptt_delta_loss(_stream(), _p(states), states.stride(0), states.stride(1), _p(d_all), b, t, n, delta,
+                                           mean, stdv, _p(deltas), _p(dd),
                                            _p(hstep), _p(loss), _p(stats), _p(partial), _p(ticket)))
         ctx.dd = dd
         ctx.mark_non_differentiable(deltas, hstep, stats)
