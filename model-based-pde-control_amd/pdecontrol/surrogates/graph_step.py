@@ -53,7 +53,11 @@ class GraphedTBPTTStep:
         if not self.adam_in_flush:
             self.bucket.zero_()
         out = self.module.training_step((self.states, self.actions), 0)
-        out["loss"].backward()
+        from pdecontrol.surrogates import hipops, ops
+        if ops.fused_enabled():
+            out["loss"].backward(gradient=hipops.unit_grad(self.device))
+        else:
+            out["loss"].backward()
         return out
 
     def _prepare(self, warmup):

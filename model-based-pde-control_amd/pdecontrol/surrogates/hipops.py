@@ -450,7 +450,24 @@ class _DeltaLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, *_):
         dd, ctx.dd = ctx.dd, None
-        return (None if dd is None or g_loss is None else dd * g_loss), None, None, None, None, None
+        if dd is None or g_loss is None:
+            return None, None, None, None, None, None
+        if g_loss.data_ptr() == _UNIT_GRADS.get(g_loss.device, (None, 0))[1]:
+            return dd, None, None, None, None, None      # d loss / d loss = 1 handed in by unit_grad(): no multiply
+        return dd * g_loss, None, None, None, None, None
+
+
+_UNIT_GRADS = {}
+
+
+def unit_grad(device):
+    """A cached scalar 1.0 to start a backward pass from (``loss.backward(gradient=unit_grad(dev))``): saves the
+    ones_like fill, and the fused loss recognises it and skips the multiplication by it."""
+    device = torch.device(device)
+    if device not in _UNIT_GRADS:
+        t = torch.ones((), device=device, dtype=torch.float32)
+        _UNIT_GRADS[device] = (t, t.data_ptr())
+    return _UNIT_GRADS[device][0]
 
 
 def fused_delta_loss(surrogate, d_all, states, delta, mean, stdv):
