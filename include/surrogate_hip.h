@@ -18,11 +18,11 @@
  *   sur_flush_*_grads                 reduces the per-workgroup partial gradient rows into the
  *                                     parameter gradient tensors (deterministic, no atomics)
  *
- * One workgroup handles one sample with every activation in LDS; backward kernels recompute the
- * forward intermediates from saved module inputs / hidden states.  Parameter gradients are summed
- * over space and time inside the workgroup and added to that workgroup's own row of `partial`
- * ([rows][sum(size)] fp32, caller-allocated, zero-initialised); the flush kernel sums the rows into
- * g[] and re-zeroes them.
+ * One workgroup handles one sample (or one (step, sample) pair) at a time with every activation in LDS; forward
+ * launches can save their intermediates (`saved` buffers) and the backward launches read them back instead of
+ * recomputing.  Parameter gradients are summed over space and time inside the workgroup and added to that
+ * workgroup's own row of `partial` ([rows][sum(size)] fp32, caller-allocated, zero-initialised); the flush
+ * kernels sum the rows into g[] (optionally applying the Adam update, `sur_adam`) and re-zero them.
  *
  * All pointers are DEVICE pointers of contiguous fp32 tensors; launches are asynchronous on the
  * given hipStream_t.  Return 0 on success, negative on error (sur_last_error()).

@@ -7,16 +7,21 @@
 //   pdecontrol/surrogates/surrogate.py:97-107     one rollout step: cell -> decoder -> integrate
 //   pdecontrol/architectures/autoreg.py:51-94     channel / kernel / stride / padding choices
 //
-// Execution model: ONE workgroup (256 threads) per sample, every activation of the module in LDS,
-// parameters read through L1/L2 (the whole model is 39 KB).  At the reference's sizes (channels <= 16,
-// widths <= 64) a layer is a few hundred to a few thousand MACs: far too small for MFMA tiles and
-// bound by launch latency when run as separate kernels, so a whole module (3 residual blocks, or
-// LSTM cell + 4-layer decoder + integration) is one launch.  Backward kernels first recompute the
-// forward intermediates from the module inputs (cheaper than writing/reading them through HBM),
-// then back-propagate.  The time loop of a TBPTT chunk runs inside the kernel (weights and hidden
-// state stay in LDS across steps).  Parameter gradients are summed over space, time and the
-// workgroup's samples in LDS, added to the workgroup's own row of a partial buffer (no atomics, so
-// results are deterministic) and reduced over rows by a flush kernel.
+// Execution model: one workgroup (256 threads) works on one sample -- or one (rollout step, sample) pair -- at a
+// time with every activation of the module in LDS and the module's weights staged into LDS once per launch.  At
+// the reference's sizes (channels <= 16, widths <= 64) a layer is a few hundred to a few thousand MACs: bound by
+// launch latency when run as separate kernels, so a whole module is one launch:
+//   enc_fwd / enc_bwd(_multi)      3 residual blocks, persistent workgroups over the samples, 2 per CU
+//   cell_fwd / cell_bwd            the ConvLSTM recurrence of a TBPTT chunk: time loop inside the kernel, weights and
+//                                  hidden state in LDS across steps, one workgroup per sample
+//   dec_fwd / dec_bwd / cell_wgrad everything of a chunk that is NOT recurrent (decoder, dx, LSTM weight gradients),
+//                                  for all (step, sample) pairs in parallel
+//   integrate, dgrad_scan, delta_loss, flush_*   prefix sums over time, the loss section, gradient reduction (+ Adam)
+// Conv-like layers are gather-GEMMs on v_mfma_f32_16x16x4_f32 (exact fp32).  Backward kernels do not recompute:
+// forward kernels write every intermediate to HBM and backward kernels read it back (HBM capacity and bandwidth are
+// free here, dependent-phase latency is not).  Parameter gradients are summed over space, time and the workgroup's
+// samples in LDS, added to the workgroup's own row of a partial buffer (no atomics, so results are deterministic)
+// and reduced over rows by a flush kernel.
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
@@ -24,7 +29,7 @@
 
 #include "../../include/surrogate_hip.h"
 
-// Diagnostic build only (-DSUR_STAMP): shader-clock stamps per phase of chunk_fwd for workgroup 0,
+// Diagnostic build only (-DSUR_STAMP): shader-clock stamps per phase for workgroup 0 of each launch,
 // accumulated in a __device__ buffer nothing else reads (guide section 7, In-kernel stamps).
 #ifdef SUR_STAMP
 __device__ long long sur_stamp_buf[64];
