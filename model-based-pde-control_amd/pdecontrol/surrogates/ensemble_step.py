@@ -41,7 +41,7 @@ class EnsembleTBPTTStep:
                 for st in self.streams:
                     st.wait_stream(cur)                      # fork
                 for g, st in zip(self.members, [cur] + self.streams):
-                    with torch.cuda.stream(st):
+                    with torch.cuda.stream(st), g.capturing():
                         g.result = g._fwd_bwd()
                         if not g.adam_in_flush:
                             g.opt.step()

@@ -17,6 +17,9 @@ from pdecontrol.surrogates.distributed import FlatGradBucket
 
 
 class GraphedTBPTTStep:
+    """``step()`` replays one optimizer step.  On the fused kernels (single GPU) the Adam update is part of the captured
+    gradient-reduction launches: ``self.opt`` then only documents the hyper-parameters, its state is not advanced."""
+
     def __init__(self, module, batch_shape, action_shape=None, lr=None, distributed=False, warmup=3, capture=True):
         """module: PDETrainingModule on a CUDA device; batch_shape: [B, T, 1, N] of states.
         capture=False prepares everything (static buffers, warmed-up kernels, fresh Adam state) but leaves
@@ -85,18 +88,40 @@ class GraphedTBPTTStep:
                 st["exp_avg"].zero_()
                 st["exp_avg_sq"].zero_()
         # fused kernels, single GPU: the flush launches take the Adam step (fresh state, like self.opt's)
+        # (the descriptors -- moment buffers, step counter -- are created here and handed to the packs only while
+        #  the graph is being captured: the captured launches carry them by value, and any other backward pass
+        #  through the same surrogate keeps accumulating plain gradients)
         packs = getattr(self.module.surrogate, "_fused_packs", None)
         from pdecontrol.surrogates import ops
         if packs is not None and ops.fused_enabled() and not self.distributed:
             betas, eps = self.opt.defaults["betas"], self.opt.defaults["eps"]
             packs.enable_adam(self.lr, betas, eps)
+            self._adam_state = [pack.adam for pack in packs.packs]
+            packs.disable_adam()
             self.adam_in_flush = True
         torch.cuda.synchronize(self.device)
+
+    def capturing(self):
+        """Context manager for the duration of a hipGraph capture of ``_fwd_bwd``: lends the Adam descriptors to the
+        surrogate's packs (no-op unless the optimizer step lives in the flush launches)."""
+        step = self
+
+        class _Lend:
+            def __enter__(self_inner):
+                if step.adam_in_flush:
+                    for pack, state in zip(step.module.surrogate._fused_packs.packs, step._adam_state):
+                        pack.adam = state
+
+            def __exit__(self_inner, *exc):
+                if step.adam_in_flush:
+                    step.module.surrogate._fused_packs.disable_adam()
+
+        return _Lend()
 
     def _capture(self):
         self.g_main = torch.cuda.CUDAGraph()
         if not self.distributed:
-            with torch.cuda.graph(self.g_main):
+            with self.capturing(), torch.cuda.graph(self.g_main):
                 self.result = self._fwd_bwd()
                 if not self.adam_in_flush:
                     self.opt.step()

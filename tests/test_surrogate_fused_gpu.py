@@ -267,3 +267,34 @@ def test_fused_delta_loss_matches_torch_ops(dev, scaled):
         np.testing.assert_allclose(float(lf[name]), float(lt[name]), rtol=1e-5, atol=1e-7, err_msg=name)
     for k in gt:
         _close(gf[k], gt[k], rtol=1e-5, atol_scale=1e-6, msg=k)
+
+
+def test_graphed_step_leaves_eager_backward_untouched(dev):
+    """The Adam update lives only in the captured launches: an eager backward through the same surrogate afterwards
+    accumulates plain gradients and does not move the parameters."""
+    from pdecontrol.surrogates import ops
+    from pdecontrol.surrogates.bench_tbptt import build_module, synthetic_batch
+    from pdecontrol.surrogates.graph_step import GraphedTBPTTStep
+    batch = synthetic_batch(B=8, device=dev)
+    try:
+        ops.enable_fused(True)
+        m = build_module(dev)
+        g = GraphedTBPTTStep(m, tuple(batch[0].shape))
+        assert g.adam_in_flush
+        g.step(*batch)
+        torch.cuda.synchronize(dev)
+        before = torch.cat([p.detach().reshape(-1) for p in m.surrogate.parameters()]).clone()
+        for p in m.surrogate.parameters():
+            if p.grad is not None:
+                p.grad.zero_()
+        m.training_step(batch, 0)["loss"].backward()
+        torch.cuda.synchronize(dev)
+        after = torch.cat([p.detach().reshape(-1) for p in m.surrogate.parameters()])
+        assert torch.equal(before, after), "eager backward must not apply an optimizer step"
+        assert any(float(p.grad.abs().max()) > 0 for p in m.surrogate.parameters() if p.grad is not None)
+        g.step()                                   # and the graph still steps
+        torch.cuda.synchronize(dev)
+        stepped = torch.cat([p.detach().reshape(-1) for p in m.surrogate.parameters()])
+        assert not torch.equal(stepped, after)
+    finally:
+        ops.enable_fused(False)
