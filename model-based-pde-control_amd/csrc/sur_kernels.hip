@@ -975,9 +975,63 @@ __host__ __device__ inline int step_saved_floats(const sur_chunk_params& p) {
     return (step_block_floats(p) + DMA_PIECE - 1) / DMA_PIECE * DMA_PIECE;
 }
 
+// ConvLSTM cell with the gate non-linearities in the GEMM epilogue (4 waves, cs = 16): wave w owns channels
+// 4w .. 4w+3 and its 16 tile rows are (channel, gate) pairs, so after the K loop lane (q, n) holds the four gate
+// pre-activations of channel 4w+q at position n in its four accumulator registers -- i, f, g, o, c' and h' are finished
+// in registers: no second pass over LDS, one barrier per step instead of two.
+__device__ void cell_forward_fused(const sur_chunk_params& p, const StepLayout& L, const float* const* w) {
+    const int s = p.cs * p.hq, hq = p.hq, ca = p.ca, cs = p.cs;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int gate_stride = (int)(w[SUR_ST_WXF] - w[SUR_ST_WXI]);
+    const int gate_r = r & 3, ch_r = 4 * wave + (r >> 2);                 // identity of this lane's A row
+    const float* ax = w[SUR_ST_WXI] + gate_r * gate_stride + ch_r * (ca * 3);   // W_g[(o*cin + ci)*3 + tap]
+    const float* ah = w[SUR_ST_WHI] + gate_r * gate_stride + ch_r * (cs * 3);
+    const int ch = 4 * wave + q;                                           // channel of this lane's accumulators
+    const float bi = w[SUR_ST_BXI][ch], bf = (w[SUR_ST_BXI] + gate_stride)[ch], bc = (w[SUR_ST_BXI] + 2 * gate_stride)[ch],
+                bo = (w[SUR_ST_BXI] + 3 * gate_stride)[ch];
+    for (int n0 = 0; n0 < hq; n0 += 16) {
+        const int n = n0 + r;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap) {
+            const int col = wrapi((n < hq ? n : 0) + tap - 1, hq);
+            {   // latent action channels (ca <= 4: one K step)
+                const bool ok = q < ca;
+                const float a = ax[(ok ? q : 0) * 3 + tap], bv = L.x[(ok ? q : 0) * hq + col];
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ok ? a : 0.f, ok ? bv : 0.f, acc0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int c0 = 0; c0 < 16; c0 += 8) {   // hidden channels (cs = 16): two independent accumulators
+                const float a0 = ah[(c0 + q) * 3 + tap], b0 = L.h[(c0 + q) * hq + col];
+                const float a1 = ah[(c0 + 4 + q) * 3 + tap], b1 = L.h[(c0 + 4 + q) * hq + col];
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc1, 0, 0, 0);
+            }
+        }
+        if (n < hq) {
+            const int idx = ch * hq + n;
+            const float gi = sigmoid_(acc0[0] + acc1[0] + bi), gf = sigmoid_(acc0[1] + acc1[1] + bf),
+                        gg = tanhf(acc0[2] + acc1[2] + bc), go = sigmoid_(acc0[3] + acc1[3] + bo);
+            L.gates[idx] = gi;
+            L.gates[s + idx] = gf;
+            L.gates[2 * s + idx] = gg;
+            L.gates[3 * s + idx] = go;
+            const float cn = fmaf(gf, L.c[idx], gi * gg);
+            L.cnew[idx] = cn;
+            L.hnew[idx] = go * tanhf(cn);
+        }
+    }
+    __syncthreads();
+}
+
 // ConvLSTM cell on LDS-resident x, h, c: fills gates (activated), cnew, hnew
 __device__ void cell_forward(const sur_chunk_params& p, const StepLayout& L, const float* const* w) {
     const int s = p.cs * p.hq;
+    if (blockDim.x == 256 && p.cs == 16 && p.ca <= 4) {
+        cell_forward_fused(p, L, w);
+        return;
+    }
     STAMP(0);
     // all four gates' pre-activations in ONE gather-GEMM: rows = (gate, channel), K = 3*(ca + cs).
     // The four gates' weights are consecutive in the LDS copy (Wx_g, b_g, Wh_g per gate), so the
