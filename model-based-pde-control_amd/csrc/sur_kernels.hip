@@ -1220,8 +1220,8 @@ __host__ __device__ inline int cell_part_floats(const sur_chunk_params& p) { ret
 __host__ __device__ inline int dec_part_floats(const sur_chunk_params& p) { return step_block_floats(p) - cell_part_floats(p); }
 __host__ __device__ inline int cell_fwd_act_floats(const sur_chunk_params& p) { return p.ca * p.hq + 8 * p.cs * p.hq; }
 __host__ __device__ inline int cell_bwd_act_floats(const sur_chunk_params& p) {
-    const int s = p.cs * p.hq;   // c, [gates|cnew] twice (working copy + DMA target), dgates, four dh partials, two carries
-    return s + 2 * 5 * s + 4 * s + 4 * s + 2 * s;
+    const int s = p.cs * p.hq;   // [gates | c_k] twice (ping-pong DMA targets), dgates, four dh partials
+    return 2 * 5 * s + 4 * s + 4 * s;
 }
 __host__ __device__ inline int cell_wgrad_act_floats(const sur_chunk_params& p) {
     return 2 * p.ca * p.hq + 5 * p.cs * p.hq;   // x, dx, h_in, dgates
@@ -1414,7 +1414,12 @@ dec_bwd_kernel(const sur_chunk_params p, const float* __restrict__ saved, const 
 
 // BPTT through the cell chain of one sample: consumes dh_dec (decoder) and the upstream dh / dc gradients, emits the
 // gate gradients dG_k of every step (for cell_wgrad_kernel) and the gradient wrt the teacher-forced hidden inputs.
-// Only what is recurrent stays here: the gate derivative and dh_{k-1} = sum_g Wh_g^T dG_g.
+// Only what is recurrent stays here: the gate derivative and dh_{k-1} = sum_g Wh_g^T dG_g.  Two barriers per step:
+//   A  element-wise: every thread owns the same elements in every step, so dc_carry lives in registers; the incoming
+//      dh is the sum of the four partial tiles the previous step's GEMM left in LDS; the next step's c_{k-1} and
+//      dh_dec were prefetched into registers, its [gates | c] block arrived by LDS-DMA in the other block buffer
+//   B  issue the prefetches for step k-1, then the dh GEMM (K split by gate over the wave quarters)
+constexpr int CELL_EPT = 4;   // elements per thread: cs * hq <= 4 * 256
 __global__ void __launch_bounds__(TPB)
 cell_bwd_kernel(const sur_chunk_params p, const float* __restrict__ c0, int hc_bstride, const float* __restrict__ c_all,
                 const float* __restrict__ saved, const float* __restrict__ dh_dec, const float* __restrict__ dh_all,
@@ -1423,46 +1428,68 @@ cell_bwd_kernel(const sur_chunk_params p, const float* __restrict__ c0, int hc_b
     extern __shared__ __align__(16) float lds[];
     const int b = blockIdx.x, s = p.cs * p.hq;
     StepLayout L{};
-    L.c = lds;
-    L.gates = L.c + s;          // working copy of [gates | c_k]
-    L.cnew = L.gates + 4 * s;
-    float* next_blk = L.cnew + s;   // DMA target for the next step's [gates | c_k]
-    L.dgates = next_blk + 5 * s;
-    float* part = L.dgates + 4 * s; // four partial dh tiles
-    L.dh_carry = part + 4 * s;
-    L.dc_carry = L.dh_carry + s;
-    float* wbase = L.dc_carry + s;
+    float* blk[2] = {lds, lds + 5 * s};   // [gates | c_k] of the step at hand / of the next one (ping-pong)
+    L.dgates = lds + 10 * s;
+    float* part = L.dgates + 4 * s;        // four partial dh tiles
+    float* wbase = part + 4 * s;
     const size_t save_stride = step_saved_floats(p);
     const int npieces = (5 * s) / DMA_PIECE;   // a whole number: checked on the host
     auto fetch_block = [&](int kk) {
         const float* src = saved + ((size_t)kk * B + b) * save_stride;
+        float* dst = blk[kk & 1];
         const int lane = threadIdx.x & 63;
         for (int j = threadIdx.x >> 6; j < npieces; j += blockDim.x >> 6)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + j * DMA_PIECE + lane * 4),
-                                             (__attribute__((address_space(3))) void*)(next_blk + j * DMA_PIECE + lane * 4), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(dst + j * DMA_PIECE + lane * 4), 16, 0, 0);
+    };
+    float cp[CELL_EPT], dhd[CELL_EPT], dcc[CELL_EPT];
+    auto prefetch = [&](int kk) {   // c_{kk-1} and the decoder's dh of step kk
+#pragma unroll
+        for (int e = 0; e < CELL_EPT; ++e) {
+            const int i = threadIdx.x + e * TPB;
+            if (i < s) {
+                cp[e] = (kk > 0) ? c_all[((size_t)(kk - 1) * B + b) * s + i] : c0[(size_t)b * hc_bstride + i];
+                dhd[e] = dh_dec[((size_t)kk * B + b) * s + i];
+            }
+        }
     };
     fetch_block(K - 1);
+    prefetch(K - 1);
     const float* w[SUR_ST_NPARAM];
     stage_range<ST_NLSTM>(p, 0, wbase, w);
-    for (int i = threadIdx.x; i < s; i += blockDim.x) L.dh_carry[i] = L.dc_carry[i] = 0.0f;
+#pragma unroll
+    for (int e = 0; e < CELL_EPT; ++e) dcc[e] = 0.0f;
     __syncthreads();
 
-    for (int k = K - 1; k >= 0; --k) {
-        const size_t kb = (size_t)k * B + b;
-        for (int i = threadIdx.x; i < s; i += blockDim.x)
-            L.c[i] = (k > 0) ? c_all[((size_t)(k - 1) * B + b) * s + i] : c0[(size_t)b * hc_bstride + i];
-        {   // the DMA of this step's [gates | c_k] was retired by the previous phase-closing barrier
-            const float4* src = reinterpret_cast<const float4*>(next_blk);
-            float4* dst = reinterpret_cast<float4*>(L.gates);
-            for (int i = threadIdx.x; i < (5 * s) >> 2; i += blockDim.x) dst[i] = src[i];
-        }
-        __syncthreads();
-        for (int i = threadIdx.x; i < s; i += blockDim.x) {
-            const float dhn = dh_dec[kb * s + i] + L.dh_carry[i] + (dh_all ? dh_all[kb * s + i] : 0.0f);
-            const float gi = L.gates[i], gf = L.gates[s + i], gg = L.gates[2 * s + i], go = L.gates[3 * s + i];
-            const float tc = tanhf(L.cnew[i]);
-            const float dcn = L.dc_carry[i] + (dc_all ? dc_all[kb * s + i] : 0.0f) + dhn * go * (1.0f - tc * tc);
-            const float d0 = dcn * gg * gi * (1.0f - gi), d1 = dcn * L.c[i] * gf * (1.0f - gf),
+    for (int k = K - 1; k >= -1; --k) {
+        // ---- A: what step k+1's GEMM produced, then (k >= 0) this step's gate derivative ----
+        const bool have_prev = k + 1 < K;               // part[] holds d loss / d h_in of step k+1
+        const bool prev_forced = have_prev && k + 1 < S; // ... which was the encoded given state, not h_k
+        const float* g_ = k >= 0 ? blk[k & 1] : nullptr;
+#pragma unroll
+        for (int e = 0; e < CELL_EPT; ++e) {
+            const int i = threadIdx.x + e * TPB;
+            if (i >= s) continue;
+            float dh_in = 0.0f;
+            if (have_prev) {
+                const float v_ = (part[i] + part[s + i]) + (part[2 * s + i] + part[3 * s + i]);
+                if (prev_forced) {
+                    if (dlstates_t) dlstates_t[((size_t)(k + 1) * B + b) * s + i] = v_;
+                } else {
+                    dh_in = v_;
+                }
+            }
+            if (k < 0) {   // past the first step: what is left goes to the initial state
+                if (dh0) dh0[(size_t)b * s + i] = dh_in;  // non-zero only if step 0 was free running (S == 0)
+                if (dc0) dc0[(size_t)b * s + i] = dcc[e];
+                continue;
+            }
+            const size_t kb = (size_t)k * B + b;
+            const float dhn = dhd[e] + dh_in + (dh_all ? dh_all[kb * s + i] : 0.0f);
+            const float gi = g_[i], gf = g_[s + i], gg = g_[2 * s + i], go = g_[3 * s + i];
+            const float tc = tanhf(g_[4 * s + i]);
+            const float dcn = dcc[e] + (dc_all ? dc_all[kb * s + i] : 0.0f) + dhn * go * (1.0f - tc * tc);
+            const float d0 = dcn * gg * gi * (1.0f - gi), d1 = dcn * cp[e] * gf * (1.0f - gf),
                         d2 = dcn * gi * (1.0f - gg * gg), d3 = dhn * tc * go * (1.0f - go);
             L.dgates[i] = d0;
             L.dgates[s + i] = d1;
@@ -1473,25 +1500,16 @@ cell_bwd_kernel(const sur_chunk_params p, const float* __restrict__ c0, int hc_b
             dg[s + i] = d1;
             dg[2 * s + i] = d2;
             dg[3 * s + i] = d3;
-            L.dc_carry[i] = dcn * gf;  // gradient wrt c_{k-1}
+            dcc[e] = dcn * gf;  // gradient wrt c_{k-1}
         }
+        if (k < 0) break;
         __syncthreads();
-        if (k > 0) fetch_block(k - 1);
-        cell_dh_gemm(p, L, w, part);
-        for (int i = threadIdx.x; i < s; i += blockDim.x) {
-            const float v_ = (part[i] + part[s + i]) + (part[2 * s + i] + part[3 * s + i]);
-            if (k < S) {  // h_in was the encoded given state: gradient goes to the state encoder
-                if (dlstates_t) dlstates_t[kb * s + i] = v_;
-                L.dh_carry[i] = 0.0f;
-            } else {      // h_in was h_{k-1}
-                L.dh_carry[i] = v_;
-            }
+        // ---- B: prefetches for step k-1, then dh_{k-1} partials ----
+        if (k > 0) {
+            fetch_block(k - 1);
+            prefetch(k - 1);
         }
-        __syncthreads();
-    }
-    for (int i = threadIdx.x; i < s; i += blockDim.x) {
-        if (dh0) dh0[(size_t)b * s + i] = L.dh_carry[i];  // non-zero only if step 0 was free running (S == 0)
-        if (dc0) dc0[(size_t)b * s + i] = L.dc_carry[i];
+        cell_dh_gemm(p, L, w, part);   // ends with the barrier that also retires the DMA
     }
 }
 
@@ -1750,7 +1768,7 @@ int sur_flush_encoder_grads(void* stream, const sur_encoder_params* p, const sur
 int sur_chunk_saved_floats(const sur_chunk_params* p) {
     if (!p) return 0;
     // the GEMM tiles want whole 16-wide latent rows; the cell backward moves [gates | c] in whole 1 KiB DMA pieces
-    if ((p->hq & 15) || ((p->ca * p->hq) & 3) || (5 * p->cs * p->hq) % DMA_PIECE) return 0;
+    if ((p->hq & 15) || ((p->ca * p->hq) & 3) || (5 * p->cs * p->hq) % DMA_PIECE || p->cs * p->hq > CELL_EPT * TPB) return 0;
     return step_saved_floats(*p);
 }
 
