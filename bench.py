@@ -299,13 +299,16 @@ def main():
             out["workload_c3"] = {"error": f"{type(exc).__name__}: {exc}"}
     if rank == 0 and n_gpus == 1:
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(E, N, L)
+            try:
+                out["cpu_baseline"] = cpu_baseline(E, N, L)
+            except Exception as exc:
+                out["cpu_baseline"] = {"error": f"{type(exc).__name__}: {exc}"}
         if not args.no_tbptt:
             try:
                 from pdecontrol.surrogates import bench_tbptt
                 out["tbptt"] = bench_tbptt.run(device=dev)
-            except ImportError:
-                out["tbptt"] = None
+            except Exception as exc:  # never lose the KS line to the secondary measurement
+                out["tbptt"] = {"error": f"{type(exc).__name__}: {exc}"}
     if dist is not None and not args.no_tbptt:
         # data-parallel surrogate step: B = 64 sequences per rank, one flat-bucket all-reduce per step
         try:
