@@ -95,11 +95,15 @@ int sur_encoder_forward(void* stream, const sur_encoder_params* p, const float* 
  * concurrently on different streams must be given disjoint row ranges). */
 int sur_encoder_backward(void* stream, const sur_encoder_params* p, const float* x, const float* dz, int m,
                          float* dx, int row_base, int row_count, const float* saved /* or NULL = recompute */);
-/* Up to three encoder backward jobs (arrays of length njobs; dx is not produced) in ONE launch: all workgroups are
- * dispatched together, so the long action-encoder job does not queue behind the state-encoder jobs. */
+/* Up to three encoder backward jobs (arrays of length njobs; dx is not produced) per launch: all workgroups are
+ * dispatched together, so the long action-encoder job does not queue behind the state-encoder jobs.  When every job
+ * has a `saved` buffer and a workspace (sur_encoder_workspace_floats(p, m) floats), the backward runs one residual
+ * block per launch (three launches, each with a third of the registers and LDS: more workgroups per CU); otherwise one
+ * whole-encoder launch. */
+int sur_encoder_workspace_floats(const sur_encoder_params* p, int m);
 int sur_encoder_backward_multi(void* stream, int njobs, const sur_encoder_params* const* ps, const float* const* xs,
                                const float* const* dzs, const int* ms, const int* row_bases, const int* row_counts,
-                               const float* const* saveds);
+                               const float* const* saveds, float* const* workspaces /* array may be NULL */);
 int sur_flush_encoder_grads(void* stream, const sur_encoder_params* p, const sur_adam* adam /* may be NULL */);
 
 /* Floats per (step, sample) of the forward intermediates sur_chunk_forward saves for sur_chunk_backward (activated

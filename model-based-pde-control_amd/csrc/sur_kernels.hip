@@ -830,6 +830,114 @@ __global__ void __launch_bounds__(TPB, ENC_BWD_OCC) enc_bwd_multi_kernel(const E
 }
 
 // ---------------------------------------------------------------------------------------------
+// Encoder backward, one residual block per launch (block 2, then 1, then 0): a third of the code and of the LDS
+// of the whole-encoder kernel per launch, so it no longer sits at the 256-VGPR cap and more workgroups share a CU.
+// The blocks' forward intermediates come from the `saved` buffer of enc_fwd_kernel; the gradient between blocks
+// travels through a small workspace ([M, c1*h1 + c2*h2] floats).
+// ---------------------------------------------------------------------------------------------
+struct EncBlockGeom {
+    int cin, cout, hin, hout, stride;
+    int saved_off;      // offset of this block's 7 intermediates in a sample's saved record
+    int in_saved_off;   // offset of this block's INPUT (= previous block's `out`) in the record, -1: the raw input x
+    int param_off;      // column of this block's parameters in a partial-gradient row
+    int psize_blk;      // their total size
+};
+
+__host__ __device__ inline EncBlockGeom enc_block_geom(const sur_encoder_params& p, int blk) {
+    EncBlockGeom g{};
+    int h = p.n, off = 0, prev_out = -1;
+    for (int b = 0; b <= blk; ++b) {
+        g.cin = p.c[b];
+        g.cout = p.c[b + 1];
+        g.hin = h;
+        g.stride = p.stride[b];
+        h /= p.stride[b];
+        g.hout = h;
+        g.saved_off = off;
+        g.in_saved_off = prev_out;
+        const int a = g.cout * g.hout;
+        prev_out = off + 6 * a;
+        off += 7 * a;
+    }
+    g.param_off = 0;
+    for (int i = 0; i < SUR_RB_NPARAM * blk; ++i) g.param_off += p.size[i];
+    g.psize_blk = 0;
+    for (int i = 0; i < SUR_RB_NPARAM; ++i) g.psize_blk += p.size[SUR_RB_NPARAM * blk + i];
+    return g;
+}
+
+// workspace floats per sample: the gradients wrt the inputs of blocks 1 and 2
+__host__ __device__ inline int enc_ws_floats(const sur_encoder_params& p) {
+    const int h1 = p.n / p.stride[0], h2 = h1 / p.stride[1];
+    return p.c[1] * h1 + p.c[2] * h2;
+}
+
+__host__ __device__ inline int enc_block_act_floats(const EncBlockGeom& g) {
+    const int a = g.cout * g.hout, nin = g.cin * g.hin;
+    return nin + 7 * a + 4 * a + a + nin;   // in, intermediates, g1 g2 g3 xh, dout, din
+}
+
+struct EncBlockJob {
+    sur_encoder_params p;
+    const float* x;
+    const float* dz;
+    const float* saved;
+    float* ws;
+    int m, row_base, wg_begin, wg_count, grads_in_lds;
+};
+
+__device__ __forceinline__ void enc_block_bwd_body(const EncBlockJob& j, int blk, int wg, float* lds) {
+    const sur_encoder_params& p = j.p;
+    const EncBlockGeom gm = enc_block_geom(p, blk);
+    const int a = gm.cout * gm.hout, nin = gm.cin * gm.hin;
+    RBBuf rb{};
+    rb.cin = gm.cin; rb.cout = gm.cout; rb.hin = gm.hin; rb.hout = gm.hout; rb.stride = gm.stride;
+    float* cur = lds;
+    rb.in = cur; cur += nin;
+    rb.skip = cur; rb.a1pre = cur + a; rb.a1 = cur + 2 * a; rb.a2pre = cur + 3 * a; rb.a2 = cur + 4 * a; rb.s = cur + 5 * a;
+    rb.out = cur + 6 * a; cur += 7 * a;
+    float *g1 = cur, *g2 = cur + a, *g3 = cur + 2 * a, *xh = cur + 3 * a;
+    cur += 4 * a;
+    float* dout = cur; cur += a;
+    float* din = cur; cur += nin;
+    ParamViews<SUR_RB_NPARAM> v;
+    stage_weights<SUR_RB_NPARAM>(p.w + SUR_RB_NPARAM * blk, p.size + SUR_RB_NPARAM * blk, cur, v);
+    const int psize = psize_of<SUR_ENC_NPARAM>(p.size);
+    float* row = p.partial + (size_t)(j.row_base + wg) * psize + gm.param_off;
+    float* gacc = j.grads_in_lds ? cur + gm.psize_blk : row;
+    setup_grads<SUR_RB_NPARAM>(p.size + SUR_RB_NPARAM * blk, gacc, j.grads_in_lds != 0, v);
+    const int nsv = enc_saved_floats(p), nws = enc_ws_floats(p);
+    const int h1 = p.n / p.stride[0];
+    const int ws_in_off = blk == 2 ? p.c[1] * h1 : 0;       // where this block writes d loss / d its input (blocks 2, 1)
+    const int ws_out_off = blk == 1 ? p.c[1] * h1 : 0;      // where block 1 reads d loss / d its output (written by block 2)
+    for (int m = wg; m < j.m; m += j.wg_count) {
+        const float* rec = j.saved + (size_t)m * nsv;
+        // this block's input, its seven intermediates, the gradient wrt its output: all loads of a round in flight
+        if (gm.in_saved_off < 0) lds_load(rb.in, j.x + (size_t)m * nin, nin);
+        else lds_load_v4(rb.in, rec + gm.in_saved_off, nin >> 2);
+        lds_load_v4(rb.skip, rec + gm.saved_off, (7 * a) >> 2);
+        const float* dsrc = blk == 2 ? j.dz + (size_t)m * a : j.ws + (size_t)m * nws + (blk == 1 ? ws_out_off : 0);
+        lds_load_v4(dout, dsrc, a >> 2);
+        rb_backward(rb, v.w, v.g, dout, din, g1, g2, g3, xh);
+        if (blk > 0) {
+            float* dst = j.ws + (size_t)m * nws + (blk == 2 ? ws_in_off : 0);
+            for (int i = threadIdx.x; i < nin; i += blockDim.x) dst[i] = din[i];
+        }
+        __syncthreads();
+    }
+    if (j.grads_in_lds) add_to_row(row, gacc, gm.psize_blk);
+}
+
+__global__ void __launch_bounds__(TPB, 3)
+enc_block_bwd_multi_kernel(const EncBlockJob j0, const EncBlockJob j1, const EncBlockJob j2, int njobs, int blk) {
+    extern __shared__ __align__(16) float lds[];
+    const int wg = blockIdx.x;
+    if (njobs > 2 && wg >= j2.wg_begin) enc_block_bwd_body(j2, blk, wg - j2.wg_begin, lds);
+    else if (njobs > 1 && wg >= j1.wg_begin) enc_block_bwd_body(j1, blk, wg - j1.wg_begin, lds);
+    else enc_block_bwd_body(j0, blk, wg, lds);
+}
+
+// ---------------------------------------------------------------------------------------------
 // TBPTT delta-mode loss: one launch for what the reference spells as ~30 tiny torch ops
 // (pdecontrol/surrogates/training.py:100-121): true deltas from the state sequence, the undscaling
 // forward, the element-wise MSE, its time-resolved and overall means, the four logged statistics and
@@ -1717,11 +1825,49 @@ int sur_encoder_backward(void* stream, const sur_encoder_params* p, const float*
     }, "enc_bwd");
 }
 
+int sur_encoder_workspace_floats(const sur_encoder_params* p, int m) {
+    if (!p || m <= 0) return 0;
+    return m * enc_ws_floats(*p);
+}
+
 int sur_encoder_backward_multi(void* stream, int njobs, const sur_encoder_params* const* ps, const float* const* xs,
                                const float* const* dzs, const int* ms, const int* row_bases, const int* row_counts,
-                               const float* const* saveds) {
+                               const float* const* saveds, float* const* workspaces) {
     if (njobs < 1 || njobs > 3 || !ps || !xs || !dzs || !ms || !row_bases || !row_counts || !saveds)
         return fail(-1, "sur_encoder_backward_multi: bad argument (1 to 3 jobs)");
+    bool split = workspaces != nullptr;
+    for (int j = 0; j < njobs && split; ++j) split = saveds[j] && workspaces[j] && ps[j] && sur_encoder_saved_floats(ps[j]) > 0;
+    if (split) {
+        // one residual block per launch, last block first; every launch carries all jobs
+        for (int blk = 2; blk >= 0; --blk) {
+            EncBlockJob jobs[3] = {};
+            size_t lds = 0;
+            int grid = 0;
+            for (int j = 0; j < njobs; ++j) {
+                const sur_encoder_params* p = ps[j];
+                if (!xs[j] || !dzs[j] || ms[j] <= 0) return fail(-1, "sur_encoder_backward_multi: job %d: bad argument", j);
+                if (!p->partial || row_counts[j] <= 0 || row_bases[j] < 0 || row_bases[j] + row_counts[j] > p->rows)
+                    return fail(-1, "sur_encoder_backward_multi: job %d: partial rows [%d, %d) outside the buffer of %d rows", j,
+                                row_bases[j], row_bases[j] + row_counts[j], p->rows);
+                const EncBlockGeom gm = enc_block_geom(*p, blk);
+                if ((gm.cout * gm.hout) & 3 || ((gm.cin * gm.hin) & 3 && blk > 0))
+                    return fail(-4, "sur_encoder_backward_multi: job %d: block %d is not float4-granular", j, blk);
+                const size_t base = sizeof(float) * (enc_block_act_floats(gm) + gm.psize_blk);
+                const int gl = (base + sizeof(float) * gm.psize_blk <= LDS_LIMIT) ? 1 : 0;
+                const size_t need = base + (gl ? sizeof(float) * gm.psize_blk : 0);
+                lds = need > lds ? need : lds;
+                const int wgs = ms[j] < row_counts[j] ? ms[j] : row_counts[j];
+                jobs[j] = EncBlockJob{*p, xs[j], dzs[j], saveds[j], workspaces[j], ms[j], row_bases[j], grid, wgs, gl};
+                grid += wgs;
+            }
+            if (int rc = set_lds(enc_block_bwd_multi_kernel, lds, "encoder block backward")) return rc;
+            if (int rc = launch_checked([&] {
+                    hipLaunchKernelGGL(enc_block_bwd_multi_kernel, dim3(grid), dim3(TPB), lds, (hipStream_t)stream, jobs[0], jobs[1],
+                                       jobs[2], njobs, blk);
+                }, "enc_block_bwd")) return rc;
+        }
+        return 0;
+    }
     EncBwdJob jobs[3] = {};
     size_t lds = 0;
     int grid = 0;

@@ -49,8 +49,10 @@ SYMBOLS = (
     ("sur_encoder_saved_floats", [_EP]),
     ("sur_encoder_forward", [_fp, _EP, _fp, _i, _fp, _fp]),
     ("sur_encoder_backward", [_fp, _EP, _fp, _fp, _i, _fp, _i, _i, _fp]),
+    ("sur_encoder_workspace_floats", [_EP, _i]),
     ("sur_encoder_backward_multi", [_fp, _i, ctypes.POINTER(_EP), ctypes.POINTER(_fp), ctypes.POINTER(_fp),
-                                    ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_fp)]),
+                                    ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_fp),
+                                    ctypes.POINTER(_fp)]),
     ("sur_flush_encoder_grads", [_fp, _EP, _AP]),
     ("sur_chunk_saved_floats", [_CP]),
     ("sur_chunk_forward", [_fp, _CP, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _fp]),
@@ -342,8 +344,12 @@ class _EncoderFn(torch.autograd.Function):
     def backward(ctx, dz):
         (x,) = ctx.saved_tensors
         dx = torch.empty_like(x) if ctx.need_dx else None
-        _check(load().sur_encoder_backward(_stream(), ctypes.byref(ctx.pack.c), _p(x), _p(dz.contiguous()), x.shape[0],
-                                           _p(dx), 0, min(ENCODER_ROWS, ctx.pack.c.rows), _p(ctx.fwd_saved)))
+        if dx is None and ctx.fwd_saved is not None:   # raw-data input: block-per-launch backward
+            _encoder_backward_multi(load(), [(ctx.pack, x, dz.contiguous(), x.shape[0], 0,
+                                              min(ENCODER_ROWS, ctx.pack.c.rows), ctx.fwd_saved)])
+        else:
+            _check(load().sur_encoder_backward(_stream(), ctypes.byref(ctx.pack.c), _p(x), _p(dz.contiguous()), x.shape[0],
+                                               _p(dx), 0, min(ENCODER_ROWS, ctx.pack.c.rows), _p(ctx.fwd_saved)))
         ctx.fwd_saved = None
         ctx.pack.dirty = True
         ctx.owner.schedule_flush()
@@ -488,10 +494,16 @@ def _encoder_backward_multi(lib, jobs):
     n = len(jobs)
     arr = lambda ctype, vals: (ctype * n)(*vals)
     ptr = lambda t: ctypes.c_void_p(None if t is None else t.data_ptr())
+    # scratch for the gradients between residual blocks (block-per-launch backward, needs the saved activations)
+    works = [None if j[6] is None else torch.empty(lib.sur_encoder_workspace_floats(ctypes.byref(j[0].c), j[3]),
+                                                   device=j[1].device, dtype=torch.float32) for j in jobs]
     _check(lib.sur_encoder_backward_multi(
         _stream(), n, arr(_EP, [ctypes.pointer(j[0].c) for j in jobs]), arr(_fp, [ptr(j[1]) for j in jobs]),
         arr(_fp, [ptr(j[2]) for j in jobs]), arr(_i, [j[3] for j in jobs]), arr(_i, [j[4] for j in jobs]),
-        arr(_i, [j[5] for j in jobs]), arr(_fp, [ptr(j[6]) for j in jobs])))
+        arr(_i, [j[5] for j in jobs]), arr(_fp, [ptr(j[6]) for j in jobs]), arr(_fp, [ptr(w) for w in works])))
+    for w in works:
+        if w is not None:
+            w.record_stream(torch.cuda.current_stream(w.device))
 
 
 def encode(x, pack, owner):

@@ -72,7 +72,7 @@ def test_surrogate_abi_rejects_bad_arguments_before_touching_the_device():
     assert lib.sur_chunk_backward(null, ctypes.byref(chunk), null, null, null, null, 0, null, null, null, null, null, null, 1, 1,
                                   1, null, null, null, null, 0, 1, null, null) < 0
     assert lib.sur_chunk_workspace_floats(ctypes.byref(chunk), 0, 4) == 0
-    assert lib.sur_encoder_backward_multi(null, 4, null, null, null, null, null, null, null) < 0
+    assert lib.sur_encoder_backward_multi(null, 4, null, null, null, null, null, null, null, null) < 0
     assert b"sur_encoder_backward_multi" in lib.sur_last_error()
     assert lib.sur_flush_encoder_grads(null, ctypes.byref(enc), null) < 0      # no partial buffer
     assert lib.sur_flush_chunk_grads(null, ctypes.byref(chunk), null) < 0
@@ -92,3 +92,4 @@ def test_surrogate_abi_rejects_bad_arguments_before_touching_the_device():
     enc.n, enc.c[0], enc.c[1], enc.c[2], enc.c[3] = 64, 1, 8, 16, 16
     enc.stride[0], enc.stride[1], enc.stride[2] = 2, 2, 1
     assert lib.sur_encoder_saved_floats(ctypes.byref(enc)) == 7 * (8 * 32 + 16 * 16 + 16 * 16)
+    assert lib.sur_encoder_workspace_floats(ctypes.byref(enc), 10) == 10 * (8 * 32 + 16 * 16)

@@ -208,8 +208,9 @@ def test_ensemble_parallel_step_equals_member_by_member(dev):
 
 
 @pytest.mark.parametrize("N", [64, 256])
-def test_encoder_saved_activations_backward_is_bit_identical_to_recompute(dev, N, monkeypatch):
-    """enc_bwd fed with the forward's saved intermediates == recomputing them in the kernel."""
+def test_encoder_saved_activations_backward_matches_recompute(dev, N, monkeypatch):
+    """Encoder backward fed with the forward's saved intermediates (one residual block per launch) against the
+    whole-encoder kernel that recomputes them: same forward, gradients equal up to summation grouping."""
     from pdecontrol.surrogates import hipops, ops
     g = torch.Generator().manual_seed(3)
     states = (torch.rand(8, 20, 1, N, generator=g) * 2 - 1).to(dev)
@@ -233,7 +234,7 @@ def test_encoder_saved_activations_backward_is_bit_identical_to_recompute(dev, N
     assert losses[0] == losses[1]
     assert grads[0].keys() == grads[1].keys() and len(grads[0]) > 20
     for k in grads[0]:
-        assert torch.equal(grads[0][k], grads[1][k]), k
+        _close(grads[0][k], grads[1][k], rtol=2e-4, atol_scale=2e-5, msg=k)
 
 
 @pytest.mark.parametrize("scaled", [True, False])
