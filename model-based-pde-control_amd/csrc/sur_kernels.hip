@@ -928,7 +928,10 @@ __device__ __forceinline__ void enc_block_bwd_body(const EncBlockJob& j, int blk
     if (j.grads_in_lds) add_to_row(row, gacc, gm.psize_blk);
 }
 
-__global__ void __launch_bounds__(TPB, 3)
+#ifndef ENC_BLK_OCC
+#define ENC_BLK_OCC 4   // 128 VGPRs (a few spilled dwords): four workgroups per CU measured best
+#endif
+__global__ void __launch_bounds__(TPB, ENC_BLK_OCC)
 enc_block_bwd_multi_kernel(const EncBlockJob j0, const EncBlockJob j1, const EncBlockJob j2, int njobs, int blk) {
     extern __shared__ __align__(16) float lds[];
     const int wg = blockIdx.x;

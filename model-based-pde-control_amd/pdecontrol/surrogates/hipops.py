@@ -155,9 +155,9 @@ class _Pack:
         self.adam = None
 
 
-# one partial row per workgroup of the encoder backward: two workgroups per CU (the kernel is built for 2 waves per
-# SIMD) hide each other's dependent-phase latency
-ENCODER_ROWS = 512
+# one partial row per workgroup of the encoder backward: several workgroups per CU (the block kernels are built for
+# 4 waves per SIMD) hide each other's dependent-phase latency
+ENCODER_ROWS = 768
 # partial rows of one chunk backward launch: the parallel decoder backward runs one workgroup per row
 CHUNK_ROWS = 384
 
