@@ -101,6 +101,10 @@ int sur_encoder_backward(void* stream, const sur_encoder_params* p, const float*
  * block per launch (three launches, each with a third of the registers and LDS: more workgroups per CU); otherwise one
  * whole-encoder launch. */
 int sur_encoder_workspace_floats(const sur_encoder_params* p, int m);
+/* One or two encoder forward jobs with `saved` buffers, one residual block per launch (three launches, each carrying
+ * all jobs, at most max_workgroups workgroups per job): the large-sample-count form of sur_encoder_forward. */
+int sur_encoder_forward_multi(void* stream, int njobs, const sur_encoder_params* const* ps, const float* const* xs, const int* ms,
+                              float* const* zs, float* const* saveds, int max_workgroups);
 int sur_encoder_backward_multi(void* stream, int njobs, const sur_encoder_params* const* ps, const float* const* xs,
                                const float* const* dzs, const int* ms, const int* row_bases, const int* row_counts,
                                const float* const* saveds, float* const* workspaces /* array may be NULL */);

@@ -940,6 +940,52 @@ enc_block_bwd_multi_kernel(const EncBlockJob j0, const EncBlockJob j1, const Enc
     else enc_block_bwd_body(j0, blk, wg, lds);
 }
 
+// Encoder forward, one residual block per launch (block 0, 1, 2), several jobs per launch: for large sample counts the
+// same trade as in the backward pass -- a third of the registers and LDS per launch, more workgroups per CU.  Each
+// block reads its input from the previous block's record in `saved` and writes its own seven intermediates there.
+struct EncFwdJob {
+    sur_encoder_params p;
+    const float* x;
+    float* z;
+    float* saved;
+    int m, wg_begin, wg_count;
+};
+
+__device__ __forceinline__ void enc_block_fwd_body(const EncFwdJob& j, int blk, int wg, float* lds) {
+    const sur_encoder_params& p = j.p;
+    const EncBlockGeom gm = enc_block_geom(p, blk);
+    const int a = gm.cout * gm.hout, nin = gm.cin * gm.hin;
+    RBBuf rb{};
+    rb.cin = gm.cin; rb.cout = gm.cout; rb.hin = gm.hin; rb.hout = gm.hout; rb.stride = gm.stride;
+    float* cur = lds;
+    rb.in = cur; cur += nin;
+    rb.skip = cur; rb.a1pre = cur + a; rb.a1 = cur + 2 * a; rb.a2pre = cur + 3 * a; rb.a2 = cur + 4 * a; rb.s = cur + 5 * a;
+    rb.out = cur + 6 * a; cur += 7 * a;
+    ParamViews<SUR_RB_NPARAM> v;
+    stage_weights<SUR_RB_NPARAM>(p.w + SUR_RB_NPARAM * blk, p.size + SUR_RB_NPARAM * blk, cur, v);
+    const int nsv = enc_saved_floats(p);
+    for (int m = wg; m < j.m; m += j.wg_count) {
+        float* rec = j.saved + (size_t)m * nsv;
+        if (gm.in_saved_off < 0) lds_load(rb.in, j.x + (size_t)m * nin, nin);
+        else lds_load_v4(rb.in, rec + gm.in_saved_off, nin >> 2);
+        rb_forward(rb, v.w);
+        float4* dst = reinterpret_cast<float4*>(rec + gm.saved_off);
+        const float4* src = reinterpret_cast<const float4*>(rb.skip);
+        for (int i = threadIdx.x; i < (7 * a) >> 2; i += blockDim.x) dst[i] = src[i];
+        if (blk == 2)
+            for (int i = threadIdx.x; i < a; i += blockDim.x) j.z[(size_t)m * a + i] = rb.out[i];
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(TPB, ENC_BLK_OCC)
+enc_block_fwd_multi_kernel(const EncFwdJob j0, const EncFwdJob j1, int njobs, int blk) {
+    extern __shared__ __align__(16) float lds[];
+    const int wg = blockIdx.x;
+    if (njobs > 1 && wg >= j1.wg_begin) enc_block_fwd_body(j1, blk, wg - j1.wg_begin, lds);
+    else enc_block_fwd_body(j0, blk, wg, lds);
+}
+
 // ---------------------------------------------------------------------------------------------
 // TBPTT delta-mode loss: one launch for what the reference spells as ~30 tiny torch ops
 // (pdecontrol/surrogates/training.py:100-121): true deltas from the state sequence, the undscaling
@@ -1826,6 +1872,36 @@ int sur_encoder_backward(void* stream, const sur_encoder_params* p, const float*
         hipLaunchKernelGGL(enc_bwd_kernel, dim3(grid), dim3(TPB), lds, (hipStream_t)stream, *p, x, dz, m, dx, grads_in_lds,
                            row_base, saved);
     }, "enc_bwd");
+}
+
+int sur_encoder_forward_multi(void* stream, int njobs, const sur_encoder_params* const* ps, const float* const* xs, const int* ms,
+                              float* const* zs, float* const* saveds, int max_workgroups) {
+    if (njobs < 1 || njobs > 2 || !ps || !xs || !ms || !zs || !saveds || max_workgroups <= 0)
+        return fail(-1, "sur_encoder_forward_multi: bad argument (1 or 2 jobs)");
+    for (int blk = 0; blk < 3; ++blk) {
+        EncFwdJob jobs[2] = {};
+        size_t lds = 0;
+        int grid = 0;
+        for (int j = 0; j < njobs; ++j) {
+            const sur_encoder_params* p = ps[j];
+            if (!p || !xs[j] || !zs[j] || !saveds[j] || ms[j] <= 0)
+                return fail(-1, "sur_encoder_forward_multi: job %d: bad argument (the `saved` buffer is required)", j);
+            if (sur_encoder_saved_floats(p) == 0) return fail(-4, "sur_encoder_forward_multi: job %d: geometry not float4-granular", j);
+            if (p->n > 64 * LN_MAX_EPL * p->stride[0]) return fail(-4, "sur_encoder_forward_multi: N = %d too wide for the fused LayerNorm", p->n);
+            const EncBlockGeom gm = enc_block_geom(*p, blk);
+            const size_t need = sizeof(float) * (gm.cin * gm.hin + 7 * gm.cout * gm.hout + gm.psize_blk);
+            lds = need > lds ? need : lds;
+            const int wgs = ms[j] < max_workgroups ? ms[j] : max_workgroups;
+            jobs[j] = EncFwdJob{*p, xs[j], zs[j], saveds[j], ms[j], grid, wgs};
+            grid += wgs;
+        }
+        if (int rc = set_lds(enc_block_fwd_multi_kernel, lds, "encoder block forward")) return rc;
+        if (int rc = launch_checked([&] {
+                hipLaunchKernelGGL(enc_block_fwd_multi_kernel, dim3(grid), dim3(TPB), lds, (hipStream_t)stream, jobs[0], jobs[1], njobs,
+                                   blk);
+            }, "enc_block_fwd")) return rc;
+    }
+    return 0;
 }
 
 int sur_encoder_workspace_floats(const sur_encoder_params* p, int m) {

@@ -50,6 +50,8 @@ SYMBOLS = (
     ("sur_encoder_forward", [_fp, _EP, _fp, _i, _fp, _fp]),
     ("sur_encoder_backward", [_fp, _EP, _fp, _fp, _i, _fp, _i, _i, _fp]),
     ("sur_encoder_workspace_floats", [_EP, _i]),
+    ("sur_encoder_forward_multi", [_fp, _i, ctypes.POINTER(_EP), ctypes.POINTER(_fp), ctypes.POINTER(_i), ctypes.POINTER(_fp),
+                                   ctypes.POINTER(_fp), _i]),
     ("sur_encoder_backward_multi", [_fp, _i, ctypes.POINTER(_EP), ctypes.POINTER(_fp), ctypes.POINTER(_fp),
                                     ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_fp),
                                     ctypes.POINTER(_fp)]),
@@ -489,6 +491,16 @@ def fused_delta_loss(surrogate, d_all, states, delta, mean, stdv):
     return _DeltaLossFn.apply(d_all, states, float(delta), float(mean), float(stdv), scratch)
 
 
+def _encoder_forward_multi(lib, jobs):
+    """jobs: one or two (pack, x_ptr, m, z_ptr, saved_ptr) tuples (raw device addresses) -> block-per-launch forward."""
+    n = len(jobs)
+    arr = lambda ctype, vals: (ctype * n)(*vals)
+    _check(lib.sur_encoder_forward_multi(
+        _stream(), n, arr(_EP, [ctypes.pointer(j[0].c) for j in jobs]), arr(_fp, [ctypes.c_void_p(j[1]) for j in jobs]),
+        arr(_i, [j[2] for j in jobs]), arr(_fp, [ctypes.c_void_p(j[3]) for j in jobs]),
+        arr(_fp, [ctypes.c_void_p(j[4]) for j in jobs]), ENCODER_ROWS))
+
+
 def _encoder_backward_multi(lib, jobs):
     """jobs: up to three (pack, x, dz, m, row_base, row_count, saved) tuples -> one sur_encoder_backward_multi launch."""
     n = len(jobs)
@@ -627,26 +639,40 @@ class _TBPTTFn(torch.autograd.Function):
         asaved = _encoder_saved_buffer(owner.action_enc, t_total * b, dev)
         af = 0 if asaved is None else asaved.shape[1]
         nin, nlat = actions_t.shape[2] * n, ca * hq
+        lstates = [torch.empty((tau, b, cs, hq), device=dev, dtype=torch.float32)]
+        ssaved = [_encoder_saved_buffer(owner.state_enc, tau * b, dev)]
+
+        def action_job(k0, k1):
+            lo = k0 * b
+            return (owner.action_enc, actions_t.data_ptr() + 4 * lo * nin, (k1 - k0) * b, lactions_t.data_ptr() + 4 * lo * nlat,
+                    None if asaved is None else asaved.data_ptr() + 4 * lo * af)
+
+        split = asaved is not None and ssaved[0] is not None   # block-per-launch encoders need the saved records
         fork = _Fork(side)
-        lat_ready = []
-        with fork:
-            for (k0, k1) in bounds:
-                lo, m = k0 * b, (k1 - k0) * b
-                sv = None if asaved is None else ctypes.c_void_p(asaved.data_ptr() + 4 * lo * af)
-                _check(lib.sur_encoder_forward(_stream(), ctypes.byref(owner.action_enc.c),
-                                               ctypes.c_void_p(actions_t.data_ptr() + 4 * lo * nin), m,
-                                               ctypes.c_void_p(lactions_t.data_ptr() + 4 * lo * nlat), sv))
+        lat_ready = {}
+        with fork:   # the later chunks' action latents: beside everything up to their cell chain
+            for c, (k0, k1) in enumerate(bounds):
+                if split and c == 0:
+                    continue
+                job = action_job(k0, k1)
+                if split:
+                    _encoder_forward_multi(lib, [job])
+                else:
+                    _check(lib.sur_encoder_forward(_stream(), ctypes.byref(owner.action_enc.c), ctypes.c_void_p(job[1]), job[2],
+                                                   ctypes.c_void_p(job[3]), None if job[4] is None else ctypes.c_void_p(job[4])))
                 if fork.forked:
                     ev = torch.cuda.Event()
                     ev.record(fork.stream)
-                    lat_ready.append(ev)
+                    lat_ready[c] = ev
             for t in (asaved, lactions_t, actions_t):
                 if t is not None:
                     t.record_stream(torch.cuda.current_stream(dev))
-        lstates = [torch.empty((tau, b, cs, hq), device=dev, dtype=torch.float32)]
-        ssaved = [_encoder_saved_buffer(owner.state_enc, tau * b, dev)]
-        _check(lib.sur_encoder_forward(_stream(), ctypes.byref(owner.state_enc.c), _p(states_t0), tau * b, _p(lstates[0]),
-                                       _p(ssaved[0])))
+        if split:   # chunk-0 state encoding and chunk-0 action latents: one block-per-launch forward, both jobs per launch
+            _encoder_forward_multi(lib, [(owner.state_enc, states_t0.data_ptr(), tau * b, lstates[0].data_ptr(),
+                                          ssaved[0].data_ptr()), action_job(*bounds[0])])
+        else:
+            _check(lib.sur_encoder_forward(_stream(), ctypes.byref(owner.state_enc.c), _p(states_t0), tau * b, _p(lstates[0]),
+                                           _p(ssaved[0])))
         main = torch.cuda.current_stream(dev)
 
         tm = surrogate.transition_model
@@ -670,8 +696,8 @@ class _TBPTTFn(torch.autograd.Function):
             c_all = torch.empty_like(h_all)
             s_used = min(seeds[c].shape[0], k)
             saved = _saved_buffer(owner.chunk, k, b, dev)
-            if lat_ready:
-                main.wait_event(lat_ready[c])    # this chunk's action latents
+            if c in lat_ready:
+                main.wait_event(lat_ready[c])    # this chunk's action latents (encoded on the side stream)
             _check(lib.sur_chunk_forward(_stream(), ctypes.byref(owner.chunk.c), _p(lactions_t[k0:k1]), _p(lstates[c]),
                                          _p(seeds[c]), _p(h0s[c]), _p(c0s[c]), 0 if c == 0 else s_lat, k, s_used, b,
                                          _p(h_all), _p(c_all), _p(d_all[k0:k1]), _p(out_all[k0:k1]), _p(saved)))

@@ -72,6 +72,7 @@ def test_surrogate_abi_rejects_bad_arguments_before_touching_the_device():
     assert lib.sur_chunk_backward(null, ctypes.byref(chunk), null, null, null, null, 0, null, null, null, null, null, null, 1, 1,
                                   1, null, null, null, null, 0, 1, null, null) < 0
     assert lib.sur_chunk_workspace_floats(ctypes.byref(chunk), 0, 4) == 0
+    assert lib.sur_encoder_forward_multi(null, 3, null, null, null, null, null, 512) < 0
     assert lib.sur_encoder_backward_multi(null, 4, null, null, null, null, null, null, null, null) < 0
     assert b"sur_encoder_backward_multi" in lib.sur_last_error()
     assert lib.sur_flush_encoder_grads(null, ctypes.byref(enc), null) < 0      # no partial buffer
