@@ -648,9 +648,14 @@ class _TBPTTFn(torch.autograd.Function):
                     None if asaved is None else asaved.data_ptr() + 4 * lo * af)
 
         split = asaved is not None and ssaved[0] is not None   # block-per-launch encoders need the saved records
+        if split:   # chunk-0 state encoding and chunk-0 action latents: one block-per-launch forward, both jobs per launch
+            _encoder_forward_multi(lib, [(owner.state_enc, states_t0.data_ptr(), tau * b, lstates[0].data_ptr(),
+                                          ssaved[0].data_ptr()), action_job(*bounds[0])])
+        # the other action latents on the side stream: with `split`, forked AFTER the launches above (which fill the
+        # device anyway) so that they run beside chunk 0's cell chain, which occupies only B of the 256 CUs
         fork = _Fork(side)
         lat_ready = {}
-        with fork:   # the later chunks' action latents: beside everything up to their cell chain
+        with fork:
             for c, (k0, k1) in enumerate(bounds):
                 if split and c == 0:
                     continue
@@ -667,10 +672,7 @@ class _TBPTTFn(torch.autograd.Function):
             for t in (asaved, lactions_t, actions_t):
                 if t is not None:
                     t.record_stream(torch.cuda.current_stream(dev))
-        if split:   # chunk-0 state encoding and chunk-0 action latents: one block-per-launch forward, both jobs per launch
-            _encoder_forward_multi(lib, [(owner.state_enc, states_t0.data_ptr(), tau * b, lstates[0].data_ptr(),
-                                          ssaved[0].data_ptr()), action_job(*bounds[0])])
-        else:
+        if not split:
             _check(lib.sur_encoder_forward(_stream(), ctypes.byref(owner.state_enc.c), _p(states_t0), tau * b, _p(lstates[0]),
                                            _p(ssaved[0])))
         main = torch.cuda.current_stream(dev)
