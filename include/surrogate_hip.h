@@ -142,6 +142,24 @@ int sur_chunk_backward(void* stream, const sur_chunk_params* p, const float* xla
                        const float* dd_all, const float* dout_all, const float* dh_all, const float* dc_all, int k,
                        int s, int b, float* dxlat_t, float* dlstates_t, float* dh0, float* dc0, int row_base, int row_count,
                        const float* saved /* what sur_chunk_forward wrote */, float* workspace /* sur_chunk_workspace_floats */);
+/* The backward pass of SEVERAL consecutive TBPTT chunks in the same three launches (TBPTT cuts the graph between
+ * chunks, so their cell chains are independent: one workgroup per (chunk, sample); the parallel kernels do not care
+ * about chunk borders).  The chunks tile the time axis [0, k_total) of time-major tensors shared by all of them:
+ * xlat_t [K,B,ca,hq], h_all / c_all [K,B,cs,hq], saved [K,B,sur_chunk_saved_floats], dd_all [K,B,1,N],
+ * dxlat_t [K,B,ca,hq], workspace sur_chunk_workspace_floats(p, k_total, b).  Per chunk: its first `s` steps are
+ * teacher forced with lstates_t [s,B,cs,hq] (gradient -> dlstates_t, may be NULL), its initial state is h0 / c0. */
+#define SUR_MAX_SPANS 4
+typedef struct sur_chunk_span {
+    int k0, k1, s;
+    const float* lstates_t;
+    const float* h0;
+    const float* c0;
+    int hc_bstride;
+    float* dlstates_t;
+} sur_chunk_span;
+int sur_chunks_backward(void* stream, const sur_chunk_params* p, int nspans, const sur_chunk_span* spans, const float* xlat_t,
+                        const float* h_all, const float* c_all, const float* dd_all, int k_total, int b, float* dxlat_t,
+                        int row_base, int row_count, const float* saved, float* workspace);
 int sur_flush_chunk_grads(void* stream, const sur_chunk_params* p, const sur_adam* adam /* may be NULL */);
 /* The reductions of a surrogate's three parameter packs (two encoders, chunk) in ONE launch. */
 int sur_flush_all_grads(void* stream, const sur_encoder_params* e0, const sur_adam* a0, const sur_encoder_params* e1,

@@ -1577,13 +1577,23 @@ dec_bwd_kernel(const sur_chunk_params p, const float* __restrict__ saved, const 
 //      dh_dec were prefetched into registers, its [gates | c] block arrived by LDS-DMA in the other block buffer
 //   B  issue the prefetches for step k-1, then the dh GEMM (K split by gate over the wave quarters)
 constexpr int CELL_EPT = 4;   // elements per thread: cs * hq <= 4 * 256
+struct ChunkSpans {
+    sur_chunk_span sp[SUR_MAX_SPANS];
+    int n;
+};
 __global__ void __launch_bounds__(TPB)
-cell_bwd_kernel(const sur_chunk_params p, const float* __restrict__ c0, int hc_bstride, const float* __restrict__ c_all,
+cell_bwd_kernel(const sur_chunk_params p, const ChunkSpans spans, const float* __restrict__ c_all,
                 const float* __restrict__ saved, const float* __restrict__ dh_dec, const float* __restrict__ dh_all,
-                const float* __restrict__ dc_all, int K, int S, int B, float* __restrict__ dg_all,
-                float* __restrict__ dlstates_t, float* __restrict__ dh0, float* __restrict__ dc0) {
+                const float* __restrict__ dc_all, int B, float* __restrict__ dg_all, float* __restrict__ dh0,
+                float* __restrict__ dc0) {
     extern __shared__ __align__(16) float lds[];
-    const int b = blockIdx.x, s = p.cs * p.hq;
+    // workgroup -> (chunk of the time axis, sample): the chunks' chains are independent (TBPTT cuts the graph)
+    const sur_chunk_span sp = spans.sp[blockIdx.x / B];
+    const int b = blockIdx.x % B, s = p.cs * p.hq;
+    const int K0 = sp.k0, K = sp.k1, S = sp.k0 + sp.s;   // steps K0 .. K-1 (global time index), the first sp.s teacher forced
+    const float* __restrict__ c0 = sp.c0;
+    const int hc_bstride = sp.hc_bstride;
+    float* __restrict__ dlstates_t = sp.dlstates_t;
     StepLayout L{};
     float* blk[2] = {lds, lds + 5 * s};   // [gates | c_k] of the step at hand / of the next one (ping-pong)
     L.dgates = lds + 10 * s;
@@ -1605,7 +1615,7 @@ cell_bwd_kernel(const sur_chunk_params p, const float* __restrict__ c0, int hc_b
         for (int e = 0; e < CELL_EPT; ++e) {
             const int i = threadIdx.x + e * TPB;
             if (i < s) {
-                cp[e] = (kk > 0) ? c_all[((size_t)(kk - 1) * B + b) * s + i] : c0[(size_t)b * hc_bstride + i];
+                cp[e] = (kk > K0) ? c_all[((size_t)(kk - 1) * B + b) * s + i] : c0[(size_t)b * hc_bstride + i];
                 dhd[e] = dh_dec[((size_t)kk * B + b) * s + i];
             }
         }
@@ -1618,11 +1628,11 @@ cell_bwd_kernel(const sur_chunk_params p, const float* __restrict__ c0, int hc_b
     for (int e = 0; e < CELL_EPT; ++e) dcc[e] = 0.0f;
     __syncthreads();
 
-    for (int k = K - 1; k >= -1; --k) {
-        // ---- A: what step k+1's GEMM produced, then (k >= 0) this step's gate derivative ----
+    for (int k = K - 1; k >= K0 - 1; --k) {
+        // ---- A: what step k+1's GEMM produced, then (k >= K0) this step's gate derivative ----
         const bool have_prev = k + 1 < K;               // part[] holds d loss / d h_in of step k+1
         const bool prev_forced = have_prev && k + 1 < S; // ... which was the encoded given state, not h_k
-        const float* g_ = k >= 0 ? blk[k & 1] : nullptr;
+        const float* g_ = k >= K0 ? blk[k & 1] : nullptr;
 #pragma unroll
         for (int e = 0; e < CELL_EPT; ++e) {
             const int i = threadIdx.x + e * TPB;
@@ -1631,12 +1641,12 @@ cell_bwd_kernel(const sur_chunk_params p, const float* __restrict__ c0, int hc_b
             if (have_prev) {
                 const float v_ = (part[i] + part[s + i]) + (part[2 * s + i] + part[3 * s + i]);
                 if (prev_forced) {
-                    if (dlstates_t) dlstates_t[((size_t)(k + 1) * B + b) * s + i] = v_;
+                    if (dlstates_t) dlstates_t[((size_t)(k + 1 - K0) * B + b) * s + i] = v_;
                 } else {
                     dh_in = v_;
                 }
             }
-            if (k < 0) {   // past the first step: what is left goes to the initial state
+            if (k < K0) {   // past the first step: what is left goes to the initial state
                 if (dh0) dh0[(size_t)b * s + i] = dh_in;  // non-zero only if step 0 was free running (S == 0)
                 if (dc0) dc0[(size_t)b * s + i] = dcc[e];
                 continue;
@@ -1659,10 +1669,10 @@ cell_bwd_kernel(const sur_chunk_params p, const float* __restrict__ c0, int hc_b
             dg[3 * s + i] = d3;
             dcc[e] = dcn * gf;  // gradient wrt c_{k-1}
         }
-        if (k < 0) break;
+        if (k < K0) break;
         __syncthreads();
         // ---- B: prefetches for step k-1, then dh_{k-1} partials ----
-        if (k > 0) {
+        if (k > K0) {
             fetch_block(k - 1);
             prefetch(k - 1);
         }
@@ -1673,10 +1683,9 @@ cell_bwd_kernel(const sur_chunk_params p, const float* __restrict__ c0, int hc_b
 // Everything of the cell backward that is not recurrent, for all (step, sample) pairs in parallel: the gradient wrt
 // the latent action and the LSTM weight / bias gradients (into this workgroup's partial row).
 __global__ void __launch_bounds__(TPB, PAR_OCC)
-cell_wgrad_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, const float* __restrict__ lstates_t,
-                  const float* __restrict__ h0, int hc_bstride, const float* __restrict__ h_all,
-                  const float* __restrict__ dg_all, int K, int S, int B, float* __restrict__ dxlat_t, int grads_in_lds,
-                  int row_base) {
+cell_wgrad_kernel(const sur_chunk_params p, const ChunkSpans spans, const float* __restrict__ xlat_t,
+                  const float* __restrict__ h_all, const float* __restrict__ dg_all, int K, int B,
+                  float* __restrict__ dxlat_t, int grads_in_lds, int row_base) {
     extern __shared__ __align__(16) float lds[];
     const int s = p.cs * p.hq, nx = p.ca * p.hq, M = K * B;
     StepLayout L{};
@@ -1706,7 +1715,11 @@ cell_wgrad_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, co
     __syncthreads();
     for (int m = blockIdx.x; m < M; m += gridDim.x) {
         const int k = m / B, b = m - k * B;
-        const float* hin = (k < S) ? lstates_t + (size_t)m * s : (k > 0 ? h_all + ((size_t)(k - 1) * B + b) * s : h0 + (size_t)b * hc_bstride);
+        int si = 0;
+        for (int j = 1; j < spans.n; ++j) si = k >= spans.sp[j].k0 ? j : si;
+        const sur_chunk_span sp = spans.sp[si];
+        const float* hin = (k - sp.k0 < sp.s) ? sp.lstates_t + ((size_t)(k - sp.k0) * B + b) * s
+                                               : (k > sp.k0 ? h_all + ((size_t)(k - 1) * B + b) * s : sp.h0 + (size_t)b * sp.hc_bstride);
         for (int i = threadIdx.x; i < nx; i += blockDim.x) L.x[i] = xlat_t[(size_t)m * nx + i];
         for (int i = threadIdx.x; i < s; i += blockDim.x) L.h[i] = hin[i];
         lds_load_v4(L.dgates, dg_all + (size_t)m * 4 * s, s);
@@ -2036,62 +2049,90 @@ int sur_chunk_workspace_floats(const sur_chunk_params* p, int k, int b) {
     return k * b * (5 * p->cs * p->hq + 4 * p->hq);   // dh_dec [K,B,cs,hq] + dg_all [K,B,4,cs,hq] + ga_all [K,B,1,N]
 }
 
+static int chunks_backward_impl(void* stream, const sur_chunk_params* p, const ChunkSpans& spans, const float* xlat_t,
+                                const float* h_all, const float* c_all, const float* dd_all, const float* dout_all,
+                                const float* dh_all, const float* dc_all, int k_total, int b, float* dxlat_t, float* dh0,
+                                float* dc0, int row_base, int row_count, const float* saved, float* workspace, const char* who) {
+    if (!saved || !workspace) return fail(-1, "%s: needs the `saved` buffer the forward filled and a workspace", who);
+    if (sur_chunk_saved_floats(p) == 0) return fail(-4, "%s: hq = %d, ca = %d, cs = %d: geometry not supported", who, p->hq, p->ca, p->cs);
+    if (!p->partial || row_base < 0 || row_count < spans.n * b || p->rows < row_base + row_count)
+        return fail(-1, "%s: partial gradient buffer has %d rows, need [%d, %d) with at least %d of them", who, p->rows, row_base,
+                    row_base + row_count, spans.n * b);
+    // decoder backward of all (step, sample) pairs in parallel, then the cell chains (one workgroup per chunk and
+    // sample), then dx and the LSTM weight gradients of all pairs in parallel
+    int psize_lstm = 0, psize_dec = 0;
+    for (int i = 0; i < ST_NLSTM; ++i) psize_lstm += p->size[i];
+    for (int i = ST_NLSTM; i < SUR_ST_NPARAM; ++i) psize_dec += p->size[i];
+    const int m = k_total * b, n = 4 * p->hq, sl = p->cs * p->hq;
+    float* dh_dec = workspace;
+    float* dg_all = workspace + (size_t)m * sl;
+    float* ga_all = workspace + (size_t)m * 5 * sl;
+    const float* ga = dd_all;
+    if (dout_all || !dd_all) {
+        if (spans.n != 1) return fail(-1, "%s: gradients wrt the outputs are supported for one chunk at a time", who);
+        if (int rc = launch_checked([&] {
+                hipLaunchKernelGGL(dgrad_scan_kernel, dim3((b * n + TPB - 1) / TPB), dim3(TPB), 0, (hipStream_t)stream, dd_all,
+                                   dout_all, k_total, spans.sp[0].s, b, n, p->delta * p->mul, ga_all);
+            }, "dgrad_scan")) return rc;
+        ga = ga_all;
+    }
+    const size_t dec_base = sizeof(float) * (dec_act_floats(*p, true) + psize_dec);
+    const int dec_gl = dec_base + sizeof(float) * psize_dec <= LDS_LIMIT ? 1 : 0;
+    const size_t lds_dec = dec_base + (dec_gl ? sizeof(float) * psize_dec : 0);
+    const size_t lds_cell = sizeof(float) * (cell_bwd_act_floats(*p) + psize_lstm);
+    const size_t wg_base = sizeof(float) * (cell_wgrad_act_floats(*p) + psize_lstm);
+    const int wg_gl = wg_base + sizeof(float) * psize_lstm <= LDS_LIMIT ? 1 : 0;
+    const size_t lds_wg = wg_base + (wg_gl ? sizeof(float) * psize_lstm : 0);
+    if (int rc = set_lds(dec_bwd_kernel, lds_dec, "decoder backward")) return rc;
+    if (int rc = set_lds(cell_bwd_kernel, lds_cell, "cell backward")) return rc;
+    if (int rc = set_lds(cell_wgrad_kernel, lds_wg, "cell weight gradients")) return rc;
+    const int grid = m < row_count ? m : row_count;
+    if (int rc = launch_checked([&] {
+            hipLaunchKernelGGL(dec_bwd_kernel, dim3(grid), dim3(TPB), lds_dec, (hipStream_t)stream, *p, saved, ga, m, dh_dec, dec_gl,
+                               row_base);
+        }, "dec_bwd")) return rc;
+    if (int rc = launch_checked([&] {
+            hipLaunchKernelGGL(cell_bwd_kernel, dim3(spans.n * b), dim3(TPB), lds_cell, (hipStream_t)stream, *p, spans, c_all, saved,
+                               dh_dec, dh_all, dc_all, b, dg_all, dh0, dc0);
+        }, "cell_bwd")) return rc;
+    return launch_checked([&] {
+        hipLaunchKernelGGL(cell_wgrad_kernel, dim3(grid), dim3(TPB), lds_wg, (hipStream_t)stream, *p, spans, xlat_t, h_all, dg_all,
+                           k_total, b, dxlat_t, wg_gl, row_base);
+    }, "cell_wgrad");
+}
+
 int sur_chunk_backward(void* stream, const sur_chunk_params* p, const float* xlat_t, const float* lstates_t,
                        const float* h0, const float* c0, int hc_bstride, const float* h_all, const float* c_all,
-                       const float* dd_all,
-                       const float* dout_all, const float* dh_all, const float* dc_all, int k, int s, int b,
+                       const float* dd_all, const float* dout_all, const float* dh_all, const float* dc_all, int k, int s, int b,
                        float* dxlat_t, float* dlstates_t, float* dh0, float* dc0, int row_base, int row_count,
                        const float* saved, float* workspace) {
     if (!p || !xlat_t || !lstates_t || !h0 || !c0 || !h_all || !c_all || k <= 0 || b <= 0 || s < 1)
         return fail(-1, "sur_chunk_backward: bad argument");
-    if (!saved || !workspace)
-        return fail(-1, "sur_chunk_backward: needs the `saved` buffer sur_chunk_forward filled and a workspace");
-    if (sur_chunk_saved_floats(p) == 0)
-        return fail(-4, "sur_chunk_backward: hq = %d, ca = %d, cs = %d: geometry not supported", p->hq, p->ca, p->cs);
-    if (!p->partial || row_base < 0 || row_count < b || p->rows < row_base + row_count)
-        return fail(-1, "sur_chunk_backward: partial gradient buffer has %d rows, need [%d, %d) with at least B = %d of them",
-                    p->rows, row_base, row_base + row_count, b);
-    {   // decoder backward of all (step, sample) pairs in parallel, then the cell chain per sample
-        int psize_lstm = 0, psize_dec = 0;
-        for (int i = 0; i < ST_NLSTM; ++i) psize_lstm += p->size[i];
-        for (int i = ST_NLSTM; i < SUR_ST_NPARAM; ++i) psize_dec += p->size[i];
-        const int m = k * b, n = 4 * p->hq, sl = p->cs * p->hq;
-        float* dh_dec = workspace;
-        float* dg_all = workspace + (size_t)m * sl;
-        float* ga_all = workspace + (size_t)m * 5 * sl;
-        const float* ga = dd_all;
-        if (dout_all || !dd_all) {
-            if (int rc = launch_checked([&] {
-                    hipLaunchKernelGGL(dgrad_scan_kernel, dim3((b * n + TPB - 1) / TPB), dim3(TPB), 0, (hipStream_t)stream, dd_all,
-                                       dout_all, k, s, b, n, p->delta * p->mul, ga_all);
-                }, "dgrad_scan")) return rc;
-            ga = ga_all;
-        }
-        const size_t dec_base = sizeof(float) * (dec_act_floats(*p, true) + psize_dec);
-        const int dec_gl = dec_base + sizeof(float) * psize_dec <= LDS_LIMIT ? 1 : 0;
-        const size_t lds_dec = dec_base + (dec_gl ? sizeof(float) * psize_dec : 0);
-        const size_t lds_cell = sizeof(float) * (cell_bwd_act_floats(*p) + psize_lstm);
-        const size_t wg_base = sizeof(float) * (cell_wgrad_act_floats(*p) + psize_lstm);
-        const int wg_gl = wg_base + sizeof(float) * psize_lstm <= LDS_LIMIT ? 1 : 0;
-        const size_t lds_wg = wg_base + (wg_gl ? sizeof(float) * psize_lstm : 0);
-        if (int rc = set_lds(dec_bwd_kernel, lds_dec, "decoder backward")) return rc;
-        if (int rc = set_lds(cell_bwd_kernel, lds_cell, "cell backward")) return rc;
-        if (int rc = set_lds(cell_wgrad_kernel, lds_wg, "cell weight gradients")) return rc;
-        const int grid = m < row_count ? m : row_count;
-        if (int rc = launch_checked([&] {
-                hipLaunchKernelGGL(dec_bwd_kernel, dim3(grid), dim3(TPB), lds_dec, (hipStream_t)stream, *p, saved, ga, m, dh_dec,
-                                   dec_gl, row_base);
-            }, "dec_bwd")) return rc;
-        if (int rc = launch_checked([&] {
-                hipLaunchKernelGGL(cell_bwd_kernel, dim3(b), dim3(TPB), lds_cell, (hipStream_t)stream, *p, c0, hc_bstride, c_all, saved,
-                                   dh_dec,
-                                   dh_all, dc_all, k, s, b, dg_all, dlstates_t, dh0, dc0);
-            }, "cell_bwd")) return rc;
-        return launch_checked([&] {
-            hipLaunchKernelGGL(cell_wgrad_kernel, dim3(grid), dim3(TPB), lds_wg, (hipStream_t)stream, *p, xlat_t, lstates_t, h0,
-                               hc_bstride, h_all, dg_all, k, s, b, dxlat_t, wg_gl, row_base);
-        }, "cell_wgrad");
+    ChunkSpans spans{};
+    spans.n = 1;
+    spans.sp[0] = sur_chunk_span{0, k, s < k ? s : k, lstates_t, h0, c0, hc_bstride, dlstates_t};
+    return chunks_backward_impl(stream, p, spans, xlat_t, h_all, c_all, dd_all, dout_all, dh_all, dc_all, k, b, dxlat_t, dh0, dc0,
+                                row_base, row_count, saved, workspace, "sur_chunk_backward");
+}
+
+int sur_chunks_backward(void* stream, const sur_chunk_params* p, int nspans, const sur_chunk_span* spans_in, const float* xlat_t,
+                        const float* h_all, const float* c_all, const float* dd_all, int k_total, int b, float* dxlat_t,
+                        int row_base, int row_count, const float* saved, float* workspace) {
+    if (!p || !spans_in || nspans < 1 || nspans > SUR_MAX_SPANS || !xlat_t || !h_all || !c_all || !dd_all || k_total <= 0 || b <= 0)
+        return fail(-1, "sur_chunks_backward: bad argument (1 to %d chunks)", SUR_MAX_SPANS);
+    ChunkSpans spans{};
+    spans.n = nspans;
+    int expect = 0;
+    for (int j = 0; j < nspans; ++j) {
+        const sur_chunk_span& sp = spans_in[j];
+        if (sp.k0 != expect || sp.k1 <= sp.k0 || sp.s < 1 || sp.s > sp.k1 - sp.k0 || !sp.lstates_t || !sp.h0 || !sp.c0 || sp.hc_bstride < 0)
+            return fail(-1, "sur_chunks_backward: chunk %d: spans must tile [0, K) in order, with 1 <= s <= k1 - k0", j);
+        spans.sp[j] = sp;
+        expect = sp.k1;
     }
+    if (expect != k_total) return fail(-1, "sur_chunks_backward: the chunks cover [0, %d), not [0, %d)", expect, k_total);
+    return chunks_backward_impl(stream, p, spans, xlat_t, h_all, c_all, dd_all, nullptr, nullptr, nullptr, k_total, b, dxlat_t, nullptr,
+                                nullptr, row_base, row_count, saved, workspace, "sur_chunks_backward");
 }
 
 int sur_flush_chunk_grads(void* stream, const sur_chunk_params* p, const sur_adam* adam) {

@@ -139,7 +139,7 @@ def run(device, steps=50, warmup=5, B=64, cpu_steps=3):
     # + the backward workspace (gate gradients 4 x 256, dh 256 per step and sample, written and read once)
     bytes_model = 4 * B * t_len * (2 * 3840 + 2 * 2 * 256 + 2 * 2 * n + 2 * 2 * n + 2 * 5 * 256)
     ms = res["hip_graph_fused"]["ms_per_step"]
-    res["roofline"] = {"bound": "latency (dependent layer phases, one workgroup per sequence)", "kernels_per_step": 24,
+    res["roofline"] = {"bound": "latency (dependent layer phases, one workgroup per sequence)", "kernels_per_step": 21,
                        "reference_torch_ops_per_step": "~4 000", "hbm_model_bytes_per_step": bytes_model,
                        "hbm_model_gbs": bytes_model / (ms * 1e-3) / 1e9, "hbm_frac_of_8TBs": bytes_model / (ms * 1e-3) / 8e12,
                        "critical_path": "enc_fwd -> (cell chain -> decoders -> integrate) x2 with one encoder in between -> loss -> "

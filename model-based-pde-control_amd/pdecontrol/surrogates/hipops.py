@@ -43,6 +43,12 @@ class AdamParams(ctypes.Structure):
                 ("beta2", ctypes.c_float), ("eps", ctypes.c_float)]
 
 
+class ChunkSpan(ctypes.Structure):
+    _fields_ = [("k0", ctypes.c_int), ("k1", ctypes.c_int), ("s", ctypes.c_int), ("lstates_t", _fp), ("h0", _fp), ("c0", _fp),
+                ("hc_bstride", ctypes.c_int), ("dlstates_t", _fp)]
+
+
+MAX_SPANS = 4
 _EP, _CP, _i = ctypes.POINTER(EncoderParams), ctypes.POINTER(ChunkParams), ctypes.c_int
 _AP = ctypes.POINTER(AdamParams)
 SYMBOLS = (
@@ -61,6 +67,7 @@ SYMBOLS = (
     ("sur_chunk_workspace_floats", [_CP, _i, _i]),
     ("sur_chunk_backward", [_fp, _CP, _fp, _fp, _fp, _fp, _i, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _fp, _fp, _fp, _fp,
                             _i, _i, _fp, _fp]),
+    ("sur_chunks_backward", [_fp, _CP, _i, ctypes.POINTER(ChunkSpan), _fp, _fp, _fp, _fp, _i, _i, _fp, _i, _i, _fp, _fp]),
     ("sur_flush_chunk_grads", [_fp, _CP, _AP]),
     ("sur_flush_all_grads", [_fp, _EP, _AP, _EP, _AP, _CP, _AP]),
     ("sur_tbptt_delta_loss", [_fp, _fp, ctypes.c_long, ctypes.c_long, _fp, _i, _i, _i, ctypes.c_float, ctypes.c_float, ctypes.c_float, _fp, _fp, _fp, _fp,
@@ -683,6 +690,10 @@ class _TBPTTFn(torch.autograd.Function):
         seeds, h0s, c0s, h_alls, c_alls, saveds = [states_t0], [h0], [c0], [], [], []
         d_all = torch.empty((t_total, b, 1, n), device=dev, dtype=torch.float32)
         out_all = torch.empty_like(d_all)
+        # one time-major tensor per quantity for ALL chunks: the backward pass then runs every chunk in the same launches
+        h_all_u = torch.empty((t_total, b, cs, hq), device=dev, dtype=torch.float32)
+        c_all_u = torch.empty_like(h_all_u)
+        saved_u = _saved_buffer(owner.chunk, t_total, b, dev)
         for c, (k0, k1) in enumerate(bounds):
             if c > 0:   # later chunks restart from the previous chunk's last prediction (gradients cut)
                 seeds.append(out_all[k0 - 1:k0])
@@ -694,10 +705,8 @@ class _TBPTTFn(torch.autograd.Function):
                 h0s.append(h_alls[-1][-1])
                 c0s.append(c_alls[-1][-1])
             k = k1 - k0
-            h_all = torch.empty((k, b, cs, hq), device=dev, dtype=torch.float32)
-            c_all = torch.empty_like(h_all)
+            h_all, c_all, saved = h_all_u[k0:k1], c_all_u[k0:k1], saved_u[k0:k1]
             s_used = min(seeds[c].shape[0], k)
-            saved = _saved_buffer(owner.chunk, k, b, dev)
             if c in lat_ready:
                 main.wait_event(lat_ready[c])    # this chunk's action latents (encoded on the side stream)
             _check(lib.sur_chunk_forward(_stream(), ctypes.byref(owner.chunk.c), _p(lactions_t[k0:k1]), _p(lstates[c]),
@@ -709,6 +718,7 @@ class _TBPTTFn(torch.autograd.Function):
         fork.join()
         ctx.owner, ctx.bounds, ctx.dims = owner, bounds, (b, t_total, n, nchunks)
         ctx.saved = (actions_t, lactions_t, seeds, lstates, h0s, c0s, h_alls, c_alls, saveds, asaved, ssaved)
+        ctx.unified = (h_all_u, c_all_u, saved_u)
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(out_all)
         return d_all, out_all, h_alls[-1][-1], c_alls[-1][-1]
@@ -729,26 +739,38 @@ class _TBPTTFn(torch.autograd.Function):
         enc_rows = [min(ENCODER_ROWS, ls.shape[0] * b) for ls in lstates]
         owner.state_enc.ensure_rows(sum(enc_rows))
         owner.refresh_partials()
-        streams = _side_streams(owner, dev, nchunks)
-        forks, dlsts = [], []
-        for c, (k0, k1) in enumerate(bounds):
-            fork = _Fork(streams[c])
-            with fork:
-                dlst = torch.empty_like(lstates[c])
-                work = _chunk_workspace(owner.chunk, k1 - k0, b, dev) if saveds[c] is not None else None
-                _check(lib.sur_chunk_backward(_stream(), ctypes.byref(owner.chunk.c), _p(lactions_t[k0:k1]), _p(lstates[c]),
-                                              _p(h0s[c]), _p(c0s[c]), 0 if c == 0 else owner.chunk.c.cs * owner.chunk.c.hq,
-                                              _p(h_alls[c]), _p(c_alls[c]), _p(dd_all[k0:k1]), None,
-                                              None, None, k1 - k0, min(seeds[c].shape[0], k1 - k0), b,
-                                              _p(dxlat_all[k0:k1]), _p(dlst), None, None, c * rows, rows, _p(saveds[c]),
-                                              _p(work)))
-                for t in (work, dlst):
-                    if t is not None:
+        dlsts = [torch.empty_like(ls) for ls in lstates]
+        s_lat = owner.chunk.c.cs * owner.chunk.c.hq
+        if nchunks <= MAX_SPANS:
+            # every chunk in the same three launches (decoder backward, cell chains, dx + weight gradients): no forks
+            h_all_u, c_all_u, saved_u = ctx.unified
+            spans = (ChunkSpan * nchunks)()
+            for c, (k0, k1) in enumerate(bounds):
+                spans[c] = ChunkSpan(k0, k1, min(seeds[c].shape[0], k1 - k0), lstates[c].data_ptr(), h0s[c].data_ptr(),
+                                     c0s[c].data_ptr(), 0 if c == 0 else s_lat, dlsts[c].data_ptr())
+            rows_all = max(nchunks * b, min(nchunks * rows, t_total * b))
+            owner.chunk.ensure_rows(rows_all)
+            owner.refresh_partials()
+            work = _chunk_workspace(owner.chunk, t_total, b, dev)
+            _check(lib.sur_chunks_backward(_stream(), ctypes.byref(owner.chunk.c), nchunks, spans, _p(lactions_t), _p(h_all_u),
+                                           _p(c_all_u), _p(dd_all), t_total, b, _p(dxlat_all), 0, rows_all, _p(saved_u), _p(work)))
+        else:
+            streams = _side_streams(owner, dev, nchunks)
+            forks = []
+            for c, (k0, k1) in enumerate(bounds):
+                fork = _Fork(streams[c])
+                with fork:
+                    work = _chunk_workspace(owner.chunk, k1 - k0, b, dev)
+                    _check(lib.sur_chunk_backward(_stream(), ctypes.byref(owner.chunk.c), _p(lactions_t[k0:k1]), _p(lstates[c]),
+                                                  _p(h0s[c]), _p(c0s[c]), 0 if c == 0 else s_lat, _p(h_alls[c]), _p(c_alls[c]),
+                                                  _p(dd_all[k0:k1]), None, None, None, k1 - k0, min(seeds[c].shape[0], k1 - k0), b,
+                                                  _p(dxlat_all[k0:k1]), _p(dlsts[c]), None, None, c * rows, rows, _p(saveds[c]),
+                                                  _p(work)))
+                    for t in (work, dlsts[c]):
                         t.record_stream(fork.stream)
-            dlsts.append(dlst)
-            forks.append(fork)
-        for fork in forks:
-            fork.join()
+                forks.append(fork)
+            for fork in forks:
+                fork.join()
         # every encoder backward of the step in launches of up to three jobs: all their workgroups are dispatched
         # together (as separate launches the long action-encoder job queued behind a state-encoder job), longest first
         jobs = [(owner.action_enc, actions_t, dxlat_all, t_total * b, 0, min(ENCODER_ROWS, owner.action_enc.c.rows), asaved)]
