@@ -299,3 +299,31 @@ def test_graphed_step_leaves_eager_backward_untouched(dev):
         assert not torch.equal(stepped, after)
     finally:
         ops.enable_fused(False)
+
+
+def test_adam_inside_the_flush_launch_matches_torch_adam(dev):
+    """Three graph-replayed optimizer steps (Adam applied by the gradient-reduction launch) against three eager steps
+    with torch.optim.Adam on the same fused kernels: same gradients, so the parameters must agree to Adam's rounding."""
+    from pdecontrol.surrogates import ops
+    from pdecontrol.surrogates.bench_tbptt import build_module, synthetic_batch
+    from pdecontrol.surrogates.graph_step import GraphedTBPTTStep
+    batch = synthetic_batch(B=8, device=dev)
+    try:
+        ops.enable_fused(True)
+        ref = build_module(dev)
+        opt = torch.optim.Adam(ref.surrogate.parameters(), lr=ref.lr)
+        for _ in range(3):
+            opt.zero_grad(set_to_none=True)
+            ref.training_step(batch, 0)["loss"].backward()
+            opt.step()
+        m = build_module(dev)
+        g = GraphedTBPTTStep(m, tuple(batch[0].shape))
+        assert g.adam_in_flush
+        g.step(*batch)
+        g.step()
+        g.step()
+        torch.cuda.synchronize(dev)
+        for (name, p), q in zip(m.surrogate.named_parameters(), ref.surrogate.parameters()):
+            np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), rtol=2e-5, atol=2e-7, err_msg=name)
+    finally:
+        ops.enable_fused(False)
