@@ -51,7 +51,7 @@ def _close(a, b, rtol=2e-4, atol_scale=2e-5, msg=""):
 
 
 @pytest.mark.parametrize("which", ["state_encoder", "action_encoder"])
-@pytest.mark.parametrize("N", [64, 256])
+@pytest.mark.parametrize("N", [64, 128, 256])
 def test_fused_encoder_forward_backward(dev, which, N):
     from pdecontrol.surrogates import hipops
     m = _build(dev, N=N)
@@ -76,7 +76,7 @@ def test_fused_encoder_forward_backward(dev, which, N):
             _close(got[k], v, atol_scale=8e-5, msg=k)
 
 
-@pytest.mark.parametrize("N", [64, 256])
+@pytest.mark.parametrize("N", [64, 128, 256])
 @pytest.mark.parametrize("K,S", [(1, 1), (4, 2), (3, 1), (5, 5)])
 def test_fused_chunk_forward_backward(dev, N, K, S):
     """K rollout steps (S teacher forced) -- cell chain, parallel decoders, integration -- vs the same steps composed
