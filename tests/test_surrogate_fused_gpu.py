@@ -327,3 +327,32 @@ def test_adam_inside_the_flush_launch_matches_torch_adam(dev):
             np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), rtol=2e-5, atol=2e-7, err_msg=name)
     finally:
         ops.enable_fused(False)
+
+
+@pytest.mark.parametrize("T", [12, 25, 45])
+def test_fused_tbptt_other_chunkings(dev, T):
+    """Sequence lengths other than the benchmark's: T = 12 -> chunks of 10 + 2, T = 25 -> 10 + 10 + 5 (all chunks in
+    the same backward launches), T = 45 -> five chunks (more than sur_chunks_backward takes: one launch set per chunk
+    on side streams).  Fused step against the plain torch path on the same GPU."""
+    from pdecontrol.surrogates import ops
+    g = torch.Generator().manual_seed(T)
+    states = (torch.rand(6, T, 1, 64, generator=g) * 2 - 1).to(dev)
+    actions = (torch.rand(6, T, 1, 64, generator=g) * 2 - 1).to(dev)
+    res = {}
+    try:
+        for fused in (False, True):
+            ops.enable_fused(fused)
+            m = _build(dev)
+            out = m.training_step((states, actions), 0)
+            out["loss"].backward()
+            torch.cuda.synchronize(dev)
+            res[fused] = (out, _grads(m))
+    finally:
+        ops.enable_fused(False)
+    (ot, gt), (of, gf) = res[False], res[True]
+    np.testing.assert_allclose(float(of["loss"].detach()), float(ot["loss"].detach()), rtol=1e-5)
+    _close(of["outputs"], ot["outputs"], rtol=1e-3, atol_scale=1e-4, msg="outputs")
+    _close(of["hsteploss"], ot["hsteploss"], rtol=1e-4, atol_scale=1e-6, msg="hsteploss")
+    assert gf.keys() == gt.keys()
+    for k in gt:
+        _close(gf[k], gt[k], rtol=1e-2, atol_scale=8e-5, msg=k)
