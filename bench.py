@@ -7,25 +7,32 @@ under torch.distributed.run with one rank per GPU.  Rank 0 prints ONE JSON line.
 What one "step" is: one ``env.step`` of the whole batch = ONE launch of the fused HIP stepper that
 advances every env by cfg_steps = 250 RK4 sub-steps (pdegym/kuramoto/kuramoto.py:78-98 of the
 reference), actions resident in HBM, phi = actions @ F evaluated in-kernel, fp32 observation,
-reward sum and overflow flags written back to HBM.  Workload at N = 1: BASELINE.json configs[1]
-(KS L=22, 64 grid points, 1024 batched envs, fp64).  Weak scaling: every rank owns its own 1024
-envs (envs never interact, no data-path collective); ``value`` = env-sub-steps of ALL ranks per
-second of the slowest rank.
+reward sum and overflow flags written back to HBM.
+
+Workload at N = 1: BASELINE.json configs[2] -- KS 256 grid points (L = 88), 4096 batched envs, fp64 --
+the largest single-GPU configuration; configs[1] (1024 x 64) rides along as ``workload_c2``.  For N > 1 every rank
+owns its own 4096 x 256 envs (configs[3]: 32768 x 256 over 8 GPUs; envs never interact, no data-path
+collective): weak scaling, ``value`` = env-sub-steps of ALL ranks per second of the slowest rank.
 
 Extra objects in the JSON line:
   roofline      HBM-model roofline of SURVEY.md 8(d): algorithmic bytes = 20*N per env-sub-step
                 (read u fp64, write u fp64, read phi fp32), achieved = bytes per launch / average
                 launch duration measured with HIP events on the launch stream.  The kernel keeps
                 the state in registers for all 250 sub-steps, so its real HBM traffic is ~250x
-                smaller; the binding resource is the fp64 VALU pipe (see "fp64_valu").
-  cpu_baseline  the CPU oracle (oracle/ks_oracle.c, bit-exact restatement of the reference
-                stepper) timed on this box's host cores on a bounded sample of the same workload.
-  tbptt         surrogate TBPTT training step (B=64, T=20, tau=5, tbtt=10), seqs/s, when the
-                surrogate package is built.
+                smaller (``traffic``, from PMC counters); the binding resource is the fp64 VALU pipe
+                (``fp64_valu``, ``valu_issue``).
+  cpu_baseline  (i) the CPU oracle (oracle/ks_oracle.c, bit-exact restatement of the reference stepper) on all host
+                cores, and (ii) SURVEY 8(d) baseline (A): the reference's own call structure (per-env Python loop, 16
+                scipy convolve1d + a torch round trip per sub-step) as P independent processes, aggregate, P stated --
+                both on a bounded sample of THIS workload, timed before the GPU is touched.
+  tbptt         surrogate TBPTT training step at N = 256 (B=64, T=20, tau=5, tbtt=10), seqs/s: captured graph,
+                eager fused (what pl.Trainer.fit drives), plain-torch legs, CPU baseline; N = 64 secondary.
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -37,9 +44,9 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 WORKLOADS = {
-    # name: (envs per GPU, N, L)  -- BASELINE.json configs[1] / configs[2] (L=88)
-    "c2": (1024, 64, 22.0),
-    "c3": (4096, 256, 88.0),
+    # name: (envs per GPU, N, L, BASELINE.json configs index)  -- L = 88 at N = 256
+    "c2": (1024, 64, 22.0, 1),
+    "c3": (4096, 256, 88.0, 2),
 }
 CFG_STEPS = 250
 DT = 1e-3
@@ -56,39 +63,191 @@ def forcing_matrix(L, N, sigma=0.4, Xi=(0.0, 0.25, 0.5, 0.75)):
     return (F / np.sqrt(2.0 * np.pi * sigma)).numpy()
 
 
+def host_cores():
+    """Cores this process may actually use: the affinity mask, capped by the cgroup CPU quota when there is one."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def kernel_source_sha():
+    """Identity of the KS kernel sources: profile-derived numbers (PMC traffic, SQ counters) are only quoted while the
+    kernel they were measured on is the kernel that runs."""
+    h = hashlib.sha256()
+    for name in ("ks_kernels.hip", "ks_internal.h"):
+        with open(os.path.join(ROOT, "model-based-pde-control_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# CPU baselines (run BEFORE the GPU is initialised: the P worker processes are started by a GPU-free parent)
+# ---------------------------------------------------------------------------------------------------------
 def cpu_baseline(E, N, L, target_seconds=12.0):
-    """Time the CPU oracle on a bounded sample of the same workload (all host cores, OpenMP)."""
+    """(i) oracle/ks_oracle.c with OpenMP over envs on every host core; (ii) baseline (A) as P processes."""
     from oracle import ks_oracle as ko
-    cores = min(os.cpu_count() or 1, 64)
+    cores = min(host_cores(), 64)
     rs = np.random.RandomState(1234)
     u0 = rs.uniform(-0.4, 0.4, (E, N))
     act = np.random.RandomState(99).uniform(-1, 1, (E, 4)).astype(np.float32)
     phi = ko.phi_from_actions(act, forcing_matrix(L, N))
-    ko.step(u0, phi, L / N, DT, 50, nthreads=cores)  # spin up the thread pool, warm caches
-    nsub = 500
+    ko.step(u0, phi, L / N, DT, 20, nthreads=cores)  # spin up the thread pool, warm caches
+    nsub = 100
     t0 = time.perf_counter()
     ko.step(u0, phi, L / N, DT, nsub, nthreads=cores)
     probe = time.perf_counter() - t0
-    nsub = int(max(250, min(CFG_STEPS * 400, nsub * target_seconds / max(probe, 1e-6))))
+    nsub = int(max(50, min(CFG_STEPS * 400, nsub * target_seconds / max(probe, 1e-6))))
     t0 = time.perf_counter()
     ko.step(u0, phi, L / N, DT, nsub, nthreads=cores)
     dt = time.perf_counter() - t0
     out = {"value": E * nsub / dt, "unit": "sub-steps/s", "cores": cores, "kind": "port",
            "sample": f"oracle/ks_oracle.c (bit-exact C restatement of the reference stepper), {E} envs x {nsub} "
                      f"sub-steps, N={N}, OpenMP over envs, {dt:.1f} s"}
-    # SURVEY 8(d) baseline (A): the reference's own call structure (per-env object, Python loop over sub-steps,
-    # 16 scipy convolve1d + a torch round trip per sub-step), one env on one core
     try:
-        n_py = 1500
-        t0 = time.perf_counter()
-        ko.step_scipy_structured(u0[0], phi[0].astype(np.float64), L / N, DT, n_py)
-        dt_py = time.perf_counter() - t0
-        out["reference_call_structure"] = {"value": n_py / dt_py, "unit": "sub-steps/s per core", "cores": 1,
-                                           "sample": f"1 env x {n_py} sub-steps through scipy.ndimage.convolve1d + torch.norm, "
-                                                     f"{dt_py:.1f} s; the reference runs one such process per env"}
+        out["reference_call_structure"] = reference_structure_baseline(N, L)
     except Exception as exc:  # scipy / torch CPU missing must not lose the baseline
         out["reference_call_structure"] = {"error": f"{type(exc).__name__}: {exc}"}
     return out
+
+
+def reference_structure_baseline(N, L, seconds=10.0):
+    """SURVEY 8(d) baseline (A): P = host cores independent processes, each one env stepped the way the reference
+    steps it (pdegym/kuramoto/kuramoto.py:78-129 through AsyncVectorEnv, pdecontrol/mbrl/mbrl.py:81-86): Python loop
+    over sub-steps, 16 scipy.ndimage.convolve1d(mode="wrap") and one numpy->torch->numpy reward per sub-step.
+    Aggregate sub-steps/s = sum over processes of sub-steps / the slowest process' loop time."""
+    P = max(1, min(host_cores(), 64))
+    cmd = [sys.executable, os.path.join(ROOT, "oracle", "ks_oracle.py"), "--structured-worker", str(N), str(L), str(seconds)]
+    env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1")
+    procs = [subprocess.Popen(cmd + [str(1234 + i)], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, env=env)
+             for i in range(P)]
+    try:
+        for p in procs:                      # every worker has imported numpy / scipy / torch and taken its first steps
+            if p.stdout.readline().strip() != "ready":
+                raise RuntimeError("structured-baseline worker failed to start")
+        for p in procs:                      # common start
+            p.stdin.write("go\n")
+            p.stdin.flush()
+        res = []
+        for p in procs:
+            line = p.communicate(timeout=seconds * 6 + 60)[0].strip().splitlines()
+            if p.returncode == 0 and line:
+                res.append(json.loads(line[-1]))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    if not res:
+        raise RuntimeError("no structured-baseline worker finished")
+    total = sum(r["substeps"] for r in res)
+    slowest = max(r["seconds"] for r in res)
+    return {"value": total / slowest, "unit": "sub-steps/s", "processes": len(res), "cores": len(res),
+            "per_process": total / slowest / len(res),
+            "sample": f"{len(res)} processes x 1 env (N={N}) x ~{res[0]['substeps']} sub-steps through scipy.ndimage.convolve1d + "
+                      f"torch.norm, Python loop per sub-step, released together, slowest loop {slowest:.1f} s"}
+
+
+# ---------------------------------------------------------------------------------------------------------
+# GPU measurement of one workload
+# ---------------------------------------------------------------------------------------------------------
+def profile_extras(name):
+    """PMC traffic / SQ issue counters of this workload from profiles/ -- only while they describe the current kernel."""
+    sha = kernel_source_sha()
+    traffic, traffic_src, valu_issue = None, None, None
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "ks_pmc_traffic.json"))).get(name, {})
+        if d.get("kernel_source_sha") == sha:
+            traffic = d.get("hbm_bytes_per_launch")
+            traffic_src = "profiles/ks_pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command " \
+                          "(FETCH_SIZE doubled per the gfx950 guide), kernel sources unchanged since (sha %s)" % sha
+        elif d:
+            traffic_src = "profiles/ks_pmc_traffic.json is STALE (kernel sources changed since it was measured): not quoted"
+    except (OSError, ValueError):
+        pass
+    try:
+        sq = json.load(open(os.path.join(ROOT, "profiles", "ks_sq_counters.json"))).get(name)
+        if sq and sq.get("kernel_source_sha") == sha:
+            valu_issue = {"frac_of_wave_cycles": sq["fractions_of_wave_cycles"]["SQ_ACTIVE_INST_VALU"],
+                          "wait_frac": sq["fractions_of_wave_cycles"]["SQ_WAIT_ANY"],
+                          "valu_instructions_per_point_substep": sq["valu_instructions_per_point_substep"],
+                          "source": "profiles/ks_sq_counters.json (rocprofv3 --pmc, SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES)"}
+    except (OSError, ValueError, KeyError):
+        pass
+    return traffic, traffic_src, valu_issue
+
+
+def roofline_of(name, E, N, kernel_ms, layout):
+    alg_bytes = 20.0 * N * E * CFG_STEPS
+    gbs = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    flops = FLOPS_PER_POINT_SUBSTEP * N * E * CFG_STEPS
+    tf = flops / (kernel_ms * 1e-3) / 1e12
+    traffic, traffic_src, valu_issue = profile_extras(name)
+    return {
+        "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+        "traffic": traffic, "traffic_note": traffic_src,
+        "kernel": "ks_rk4_fused<P=%s,G=%s>" % (layout.get("points_per_lane"), layout.get("lanes_per_env")),
+        "avg_launch_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
+        "note": "algorithmic 20*N B per env-sub-step (SURVEY 8d) x E x 250 per launch; the state stays in VGPRs for all 250 "
+                "sub-steps so real HBM traffic is ~1/250 of this; the binding resource is fp64 VALU issue",
+        "fp64_valu": {"achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS,
+                      "flops_per_point_substep": FLOPS_PER_POINT_SUBSTEP},
+        "valu_issue": valu_issue,
+    }
+
+
+class KSRun:
+    """Stepper + synthetic inputs of one workload, resident in HBM (IC ~ U(-0.4, 0.4) per env seed, 1000
+    sub-steps onto the attractor, actions ~ U(-1, 1) redrawn every step)."""
+
+    def __init__(self, kspde, name, local_rank, dev, rank, steps, mode, variant="auto"):
+        self.E, self.N, self.L, self.cfg = WORKLOADS[name]
+        E, N, L = self.E, self.N, self.L
+        self.name, self.dev = name, dev
+        self.stepper = kspde.KSStepper(E, N, L, DT, device=local_rank, mode=mode, variant=variant)
+        self.stream = torch.cuda.Stream(device=dev)
+        self.stepper.set_stream(self.stream.cuda_stream)
+        self.stepper.set_forcing(forcing_matrix(L, N))
+        base = rank * E
+        self.stepper.set_state(np.stack([np.random.RandomState(1234 + base + e).uniform(-0.4, 0.4, N) for e in range(E)]))
+        for _ in range(4):  # 1000 sub-steps onto the attractor, as 250-sub-step launches like the timed ones
+            self.stepper.step(None, CFG_STEPS, want_obs=False)
+        self.acts = torch.from_numpy(np.random.RandomState(99 + rank).uniform(-1, 1, (steps, E, 4)).astype(np.float32)).to(dev)
+        self.d_obs = torch.empty((E, N), dtype=torch.float32, device=dev)
+        self.d_ssq = torch.empty(E, dtype=torch.float64, device=dev)
+        self.d_st = torch.zeros(E, dtype=torch.int32, device=dev)
+        self.st_acc = torch.zeros(E, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize(dev)
+
+    def one_step(self, i):
+        self.stepper.step_device(d_actions=self.acts[i].data_ptr(), n_substeps=CFG_STEPS, d_obs=self.d_obs.data_ptr(),
+                                 d_ssq=self.d_ssq.data_ptr(), d_status=self.d_st.data_ptr())
+
+    def timed(self, K, W, barrier):
+        """W warm-up launches, then K launches bracketed by barrier(); returns (elapsed s, mean launch ms from HIP
+        events recorded on the launch stream)."""
+        with torch.cuda.stream(self.stream):
+            for i in range(W):
+                self.one_step(i)
+            barrier()
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+            t0 = time.perf_counter()
+            for i in range(K):
+                ev[i][0].record(self.stream)
+                self.one_step(W + i)
+                ev[i][1].record(self.stream)
+            barrier()
+            elapsed = time.perf_counter() - t0
+            self.st_acc |= self.d_st
+        torch.cuda.synchronize(self.dev)
+        assert int(self.st_acc.sum()) == 0, "non-finite state during the benchmark"
+        return elapsed, float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
 
 def measured_hbm_copy_gbs(dev, mib=1024, reps=10):
@@ -108,55 +267,42 @@ def measured_hbm_copy_gbs(dev, mib=1024, reps=10):
     return 2.0 * a.numel() * 4 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
-def measure_secondary(kspde, local_rank, dev, name, mode, steps=20, warmup=3):
-    """Same measurement as the headline one for another BASELINE config (single GPU, events on the launch stream)."""
-    E, N, L = WORKLOADS[name]
-    stepper = kspde.KSStepper(E, N, L, DT, device=local_rank, mode=mode)
-    stream = torch.cuda.Stream(device=dev)
-    stepper.set_stream(stream.cuda_stream)
-    stepper.set_forcing(forcing_matrix(L, N))
-    stepper.set_state(np.stack([np.random.RandomState(1234 + e).uniform(-0.4, 0.4, N) for e in range(E)]))
-    for _ in range(4):
-        stepper.step(None, CFG_STEPS, want_obs=False)
-    acts = torch.from_numpy(np.random.RandomState(7).uniform(-1, 1, (steps + warmup, E, 4)).astype(np.float32)).to(dev)
-    d_obs = torch.empty((E, N), dtype=torch.float32, device=dev)
-    d_ssq = torch.empty(E, dtype=torch.float64, device=dev)
-    d_st = torch.zeros(E, dtype=torch.int32, device=dev)
-    with torch.cuda.stream(stream):
-        ev = []
-        for i in range(steps + warmup):
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record(stream)
-            stepper.step_device(d_actions=acts[i].data_ptr(), n_substeps=CFG_STEPS, d_obs=d_obs.data_ptr(),
-                                d_ssq=d_ssq.data_ptr(), d_status=d_st.data_ptr())
-            b.record(stream)
-            ev.append((a, b))
-    torch.cuda.synchronize(dev)
-    assert int(d_st.sum()) == 0
-    ms = float(np.mean([a.elapsed_time(b) for a, b in ev[warmup:]]))
-    gbs = 20.0 * N * E * CFG_STEPS / (ms * 1e-3) / 1e9
-    tf = FLOPS_PER_POINT_SUBSTEP * N * E * CFG_STEPS / (ms * 1e-3) / 1e12
-    return {"workload": f"KS L={L:g} N={N}, {E} envs (BASELINE.json configs[2])", "value": E * CFG_STEPS / (ms * 1e-3),
-            "unit": "sub-steps/s", "avg_launch_ms": ms, "kernel": stepper.layout(),
-            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                         "fp64_valu_frac": tf / FP64_PEAK_TFLOPS}}
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", choices=list(WORKLOADS), default="c2")
+    ap.add_argument("--workload", choices=list(WORKLOADS), default="c3")
     ap.add_argument("--mode", choices=["fast", "exact"], default="fast")
     ap.add_argument("--variant", default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tbptt", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    n_gpus = world if world > 1 else args.gpus
+    if world == 1 and args.gpus != 1:
+        sys.exit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py ...")
+    E, N, L, cfg_idx = WORKLOADS[args.workload]
+    K, W = args.steps, args.warmup
+
+    # ---- CPU baselines first: nothing has touched the GPU yet, so starting worker processes is safe ----
+    cpu_ks, cpu_tbptt = None, None
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+        try:
+            cpu_ks = cpu_baseline(E, N, L)
+        except Exception as exc:
+            cpu_ks = {"error": f"{type(exc).__name__}: {exc}"}
+        if not args.no_tbptt:
+            try:
+                from pdecontrol.surrogates import bench_tbptt
+                cpu_tbptt = bench_tbptt.cpu_baseline(N=256, B=64, steps=10)
+            except Exception as exc:
+                cpu_tbptt = {"error": f"{type(exc).__name__}: {exc}"}
+
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the HIP stepper has no CPU fallback")
     # one rank per GPU; ranks beyond the visible GPU count share devices (only used to rehearse the
@@ -168,36 +314,9 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group(backend)
-    n_gpus = world if world > 1 else args.gpus
-    if world == 1 and args.gpus != 1:
-        sys.exit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py ...")
 
     import kspde
-    E, N, L = WORKLOADS[args.workload]
-    K, W = args.steps, args.warmup
     dev = torch.device("cuda", local_rank)
-
-    # ---- synthetic inputs: IC ~ U(-0.4, 0.4) per env seed, short warm-up onto the
-    #      attractor, actions ~ U(-1, 1) redrawn every step, all resident in HBM before timing
-    stepper = kspde.KSStepper(E, N, L, DT, device=local_rank, mode=args.mode, variant=args.variant)
-    stream = torch.cuda.Stream(device=dev)
-    stepper.set_stream(stream.cuda_stream)
-    stepper.set_forcing(forcing_matrix(L, N))
-    base = rank * E
-    u0 = np.stack([np.random.RandomState(1234 + base + e).uniform(-0.4, 0.4, N) for e in range(E)])
-    stepper.set_state(u0)
-    for _ in range(4):  # 1000 sub-steps onto the attractor, as 250-sub-step launches like the timed ones
-        stepper.step(None, CFG_STEPS, want_obs=False)
-    acts = torch.from_numpy(np.random.RandomState(99 + rank).uniform(-1, 1, (K + W, E, 4)).astype(np.float32)).to(dev)
-    d_obs = torch.empty((E, N), dtype=torch.float32, device=dev)
-    d_ssq = torch.empty(E, dtype=torch.float64, device=dev)
-    d_st = torch.zeros(E, dtype=torch.int32, device=dev)
-    st_acc = torch.zeros(E, dtype=torch.int32, device=dev)
-    torch.cuda.synchronize(dev)
-
-    def one_step(i):
-        stepper.step_device(d_actions=acts[i].data_ptr(), n_substeps=CFG_STEPS, d_obs=d_obs.data_ptr(),
-                            d_ssq=d_ssq.data_ptr(), d_status=d_st.data_ptr())
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -205,54 +324,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    with torch.cuda.stream(stream):
-        for i in range(W):
-            one_step(i)
-        barrier()
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
-        t0 = time.perf_counter()
-        for i in range(K):
-            ev[i][0].record(stream)
-            one_step(W + i)
-            ev[i][1].record(stream)
-        barrier()
-        elapsed = time.perf_counter() - t0
-        st_acc |= d_st
-    torch.cuda.synchronize(dev)
-    assert int(st_acc.sum()) == 0, "non-finite state during the benchmark"
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-
+    run = KSRun(kspde, args.workload, local_rank, dev, rank, K + W, args.mode, args.variant)
+    elapsed, kernel_ms = run.timed(K, W, barrier)
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
-    lay = stepper.layout()
-    traffic = None
-    pmc_file = os.path.join(ROOT, "profiles", "ks_pmc_traffic.json")
-    if os.path.exists(pmc_file):
-        try:
-            traffic = json.load(open(pmc_file)).get(args.workload, {}).get("hbm_bytes_per_launch")
-        except (OSError, ValueError):
-            traffic = None
-    valu_issue = None
-    try:   # SQ counters of this command (tools/prof_sq.sh): how much of the waves' time the VALU is issuing
-        sq = json.load(open(os.path.join(ROOT, "profiles", "ks_sq_counters.json"))).get(args.workload)
-        if sq:
-            valu_issue = {"frac_of_wave_cycles": sq["fractions_of_wave_cycles"]["SQ_ACTIVE_INST_VALU"],
-                          "wait_frac": sq["fractions_of_wave_cycles"]["SQ_WAIT_ANY"],
-                          "valu_instructions_per_point_substep": sq["valu_instructions_per_point_substep"],
-                          "source": "profiles/ks_sq_counters.json (rocprofv3 --pmc, SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES)"}
-    except (OSError, ValueError, KeyError):
-        valu_issue = None
+    lay = run.stepper.layout()
     total_substeps = n_gpus * E * CFG_STEPS * K
-    value = total_substeps / elapsed
-    alg_bytes_per_launch = 20.0 * N * E * CFG_STEPS
-    achieved_gbs = alg_bytes_per_launch / (kernel_ms * 1e-3) / 1e9
-    flops_per_launch = FLOPS_PER_POINT_SUBSTEP * N * E * CFG_STEPS
     out = {
         "metric": "KS sub-steps/sec (batched env)",
-        "value": value,
+        "value": total_substeps / elapsed,
         "unit": "sub-steps/s",
         "n_gpus": n_gpus,
         "steps": K,
@@ -265,25 +348,12 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": f"KS L={L:g} N={N} dt={DT:g} cfg_steps={CFG_STEPS}, {E} batched envs per GPU "
-                        f"(BASELINE.json configs[{1 if args.workload == 'c2' else 2}]), random-action rollout",
+                        f"(BASELINE.json configs[{cfg_idx if n_gpus == 1 else 3}]"
+                        f"{'' if n_gpus == 1 else f': {n_gpus * E} envs over {n_gpus} GPUs'}), random-action rollout",
             "envs_per_gpu": E, "grid_points": N, "mode": args.mode, "kernel": lay,
             "sharding": "envs sharded by rank, no collective" if n_gpus > 1 else "single GPU",
         },
-        "roofline": {
-            "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-            "traffic_note": "HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                            "command (profiles/ks_pmc_traffic.json; FETCH_SIZE doubled per the gfx950 guide)",
-            "kernel": "ks_rk4_fused", "avg_launch_ms": kernel_ms,
-            "algorithmic_bytes_per_launch": alg_bytes_per_launch,
-            "note": "algorithmic 20*N B per env-sub-step (SURVEY 8d); state stays in VGPRs for all 250 "
-                    "sub-steps so real HBM traffic is ~1/250 of this; binding resource is fp64 VALU",
-            "fp64_valu": {"achieved": flops_per_launch / (kernel_ms * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS,
-                          "unit": "TFLOP/s",
-                          "frac": flops_per_launch / (kernel_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
-                          "flops_per_point_substep": FLOPS_PER_POINT_SUBSTEP},
-            "valu_issue": valu_issue,
-        },
+        "roofline": roofline_of(args.workload, E, N, kernel_ms, lay),
     }
     if rank == 0 and n_gpus == 1:
         try:
@@ -291,35 +361,39 @@ def main():
                                                     "what": "1 GiB device-to-device copy, read + write bytes"}
         except Exception as exc:
             out["roofline"]["hbm_copy_measured"] = {"error": f"{type(exc).__name__}: {exc}"}
-    if rank == 0 and n_gpus == 1 and args.workload == "c2":
-        # secondary workload in the same run: BASELINE configs[2] (4096 x 256, L = 88) -- not the headline value
-        try:
-            out["workload_c3"] = measure_secondary(kspde, local_rank, dev, "c3", args.mode)
-        except Exception as exc:
-            out["workload_c3"] = {"error": f"{type(exc).__name__}: {exc}"}
-    if rank == 0 and n_gpus == 1:
-        if not args.no_cpu_baseline:
+        if cpu_ks is not None:
+            out["cpu_baseline"] = cpu_ks
+        if not args.no_secondary:
+            # the other single-GPU BASELINE config in the same run -- not the headline value
+            other = "c2" if args.workload == "c3" else "c3"
             try:
-                out["cpu_baseline"] = cpu_baseline(E, N, L)
+                E2, N2, L2, idx2 = WORKLOADS[other]
+                sec = KSRun(kspde, other, local_rank, dev, rank, 20 + 3, args.mode)
+                el2, ms2 = sec.timed(20, 3, lambda: torch.cuda.synchronize(dev))
+                out["workload_" + other] = {
+                    "workload": f"KS L={L2:g} N={N2}, {E2} envs (BASELINE.json configs[{idx2}])",
+                    "value": E2 * CFG_STEPS * 20 / el2, "unit": "sub-steps/s", "avg_launch_ms": ms2, "kernel": sec.stepper.layout(),
+                    "roofline": roofline_of(other, E2, N2, ms2, sec.stepper.layout())}
+                del sec
             except Exception as exc:
-                out["cpu_baseline"] = {"error": f"{type(exc).__name__}: {exc}"}
+                out["workload_" + other] = {"error": f"{type(exc).__name__}: {exc}"}
         if not args.no_tbptt:
             try:
                 from pdecontrol.surrogates import bench_tbptt
-                out["tbptt"] = bench_tbptt.run(device=dev)
+                out["tbptt"] = bench_tbptt.run(device=dev, cpu=cpu_tbptt)
             except Exception as exc:  # never lose the KS line to the secondary measurement
                 out["tbptt"] = {"error": f"{type(exc).__name__}: {exc}"}
     if dist is not None and not args.no_tbptt:
-        # data-parallel surrogate step: B = 64 sequences per rank, one flat-bucket all-reduce per step
+        # data-parallel surrogate step at N = 256: B = 64 sequences per rank, one flat-bucket all-reduce per step
         try:
             from pdecontrol.surrogates import bench_tbptt
             with torch.cuda.stream(torch.cuda.Stream(device=dev)):
-                dt_ddp, in_sync, loss_ddp = bench_tbptt.run_ddp(dev)
+                dt_ddp, in_sync, loss_ddp, nbytes = bench_tbptt.run_ddp(dev, N=256)
             td = torch.tensor([dt_ddp], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
             dist.all_reduce(td, op=dist.ReduceOp.MAX)
             out["tbptt"] = {"unit": "seqs/s", "value": n_gpus * 64 / float(td.item()), "ms_per_step": float(td.item()) * 1e3,
-                            "scaling": "weak", "B_per_rank": 64, "ranks_in_sync": in_sync, "loss": loss_ddp,
-                            "exchange": "one all-reduce of the flat 38 956-byte fp32 gradient bucket per step",
+                            "scaling": "weak", "B_per_rank": 64, "N": 256, "ranks_in_sync": in_sync, "loss": loss_ddp,
+                            "exchange": f"one all-reduce of the flat {nbytes}-byte fp32 gradient bucket per step",
                             "path": "fused HIP kernels, fwd/bwd hipGraph + all-reduce + Adam hipGraph"}
         except Exception as exc:  # never lose the KS line to the secondary measurement
             out["tbptt"] = {"error": f"{type(exc).__name__}: {exc}"}

@@ -85,7 +85,8 @@ typedef struct sur_adam {
     float* v;
     int* step;
     unsigned int* ticket;
-    float lr, beta1, beta2, eps;
+    const float* lr;   /* DEVICE scalar: a learning-rate scheduler updates it between replays of a captured step */
+    float beta1, beta2, eps;
 } sur_adam;
 
 int sur_encoder_forward(void* stream, const sur_encoder_params* p, const float* x, int m, float* z,
@@ -108,7 +109,9 @@ int sur_encoder_forward_multi(void* stream, int njobs, const sur_encoder_params*
 int sur_encoder_backward_multi(void* stream, int njobs, const sur_encoder_params* const* ps, const float* const* xs,
                                const float* const* dzs, const int* ms, const int* row_bases, const int* row_counts,
                                const float* const* saveds, float* const* workspaces /* array may be NULL */);
-int sur_flush_encoder_grads(void* stream, const sur_encoder_params* p, const sur_adam* adam /* may be NULL */);
+/* overwrite != 0 (and no Adam descriptor): g = sum of the rows instead of g += sum -- for gradient tensors that start
+ * undefined (optimizer.zero_grad(set_to_none=True)), saves the zero-fill. */
+int sur_flush_encoder_grads(void* stream, const sur_encoder_params* p, const sur_adam* adam /* may be NULL */, int overwrite);
 
 /* Floats per (step, sample) of the forward intermediates sur_chunk_forward saves for sur_chunk_backward (activated
  * gates, c_k, h_k, decoder pre-/post-LayerNorm activations; 14.8 KB at N = 64), or 0 if the latent sizes are not
@@ -160,10 +163,11 @@ typedef struct sur_chunk_span {
 int sur_chunks_backward(void* stream, const sur_chunk_params* p, int nspans, const sur_chunk_span* spans, const float* xlat_t,
                         const float* h_all, const float* c_all, const float* dd_all, int k_total, int b, float* dxlat_t,
                         int row_base, int row_count, const float* saved, float* workspace);
-int sur_flush_chunk_grads(void* stream, const sur_chunk_params* p, const sur_adam* adam /* may be NULL */);
-/* The reductions of a surrogate's three parameter packs (two encoders, chunk) in ONE launch. */
+int sur_flush_chunk_grads(void* stream, const sur_chunk_params* p, const sur_adam* adam /* may be NULL */, int overwrite);
+/* The reductions of a surrogate's three parameter packs (two encoders, chunk) in ONE launch; bit j of overwrite_mask
+ * is the `overwrite` flag of pack j. */
 int sur_flush_all_grads(void* stream, const sur_encoder_params* e0, const sur_adam* a0, const sur_encoder_params* e1,
-                        const sur_adam* a1, const sur_chunk_params* c2, const sur_adam* a2);
+                        const sur_adam* a1, const sur_chunk_params* c2, const sur_adam* a2, int overwrite_mask);
 
 /* Delta-mode TBPTT loss in one launch (reference: pdecontrol/surrogates/training.py:100-121):
  *   deltas[b,t]  = ((states[b,t+1] - states[b,t]) / delta - mean) / stdv          t < T-1   (undscaling forward)

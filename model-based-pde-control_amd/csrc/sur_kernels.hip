@@ -1736,12 +1736,14 @@ cell_wgrad_kernel(const sur_chunk_params p, const ChunkSpans spans, const float*
 // (no weight decay, no amsgrad; same formula as torch's fused kernel) -- the optimizer costs no extra launch and the
 // gradients need no zeroing pass.
 template <int NP, typename Params>
-__device__ __forceinline__ void flush_grads_body(const Params& p, int psize, const sur_adam& adam, int blk, int nblk) {
+__device__ __forceinline__ void flush_grads_body(const Params& p, int psize, const sur_adam& adam, bool overwrite, int blk,
+                                                 int nblk) {
     // block = 32 columns x 8 row groups: each thread sums every 8th row of its column, LDS combines the 8 partials
     __shared__ float part[8][33];
     const int col = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const int t = blk * 32 + col;
     const int step = adam.m ? *adam.step + 1 : 0;   // read before this block takes its ticket (see below)
+    const float lr = adam.m ? *adam.lr : 0.0f;      // device scalar: a scheduler can change it between graph replays
     float acc = 0.0f;
     if (t < psize) {
         constexpr int U = 8;   // loads of a round all in flight before the first add / re-zero (same summation order)
@@ -1781,7 +1783,9 @@ __device__ __forceinline__ void flush_grads_body(const Params& p, int psize, con
                     const float bc1 = 1.0f - powf(adam.beta1, (float)step), bc2 = 1.0f - powf(adam.beta2, (float)step);
                     const float denom = sqrtf(v) / sqrtf(bc2) + adam.eps;
                     float* w = const_cast<float*>(p.w[i]);
-                    w[t - off] -= (adam.lr / bc1) * (m / denom);
+                    w[t - off] -= (lr / bc1) * (m / denom);
+                } else if (overwrite) {
+                    p.g[i][t - off] = tot;
                 } else {
                     p.g[i][t - off] += tot;
                 }
@@ -1799,19 +1803,19 @@ __device__ __forceinline__ void flush_grads_body(const Params& p, int psize, con
 }
 
 template <int NP, typename Params>
-__global__ void __launch_bounds__(TPB) flush_grads_kernel(const Params p, int psize, const sur_adam adam) {
-    flush_grads_body<NP, Params>(p, psize, adam, blockIdx.x, gridDim.x);
+__global__ void __launch_bounds__(TPB) flush_grads_kernel(const Params p, int psize, const sur_adam adam, int overwrite) {
+    flush_grads_body<NP, Params>(p, psize, adam, overwrite != 0, blockIdx.x, gridDim.x);
 }
 
 // the three gradient reductions of a surrogate (state encoder, action encoder, chunk) in one launch
 __global__ void __launch_bounds__(TPB)
 flush_all_kernel(const sur_encoder_params e0, const sur_adam a0, int n0, const sur_encoder_params e1, const sur_adam a1, int n1,
-                 const sur_chunk_params c2, const sur_adam a2, int n2) {
+                 const sur_chunk_params c2, const sur_adam a2, int n2, int overwrite_mask) {
     const int b0 = (n0 + 31) / 32, b1 = (n1 + 31) / 32, b2 = (n2 + 31) / 32;
     const int blk = blockIdx.x;
-    if (blk < b0) flush_grads_body<SUR_ENC_NPARAM, sur_encoder_params>(e0, n0, a0, blk, b0);
-    else if (blk < b0 + b1) flush_grads_body<SUR_ENC_NPARAM, sur_encoder_params>(e1, n1, a1, blk - b0, b1);
-    else flush_grads_body<SUR_ST_NPARAM, sur_chunk_params>(c2, n2, a2, blk - b0 - b1, b2);
+    if (blk < b0) flush_grads_body<SUR_ENC_NPARAM, sur_encoder_params>(e0, n0, a0, overwrite_mask & 1, blk, b0);
+    else if (blk < b0 + b1) flush_grads_body<SUR_ENC_NPARAM, sur_encoder_params>(e1, n1, a1, overwrite_mask & 2, blk - b0, b1);
+    else flush_grads_body<SUR_ST_NPARAM, sur_chunk_params>(c2, n2, a2, overwrite_mask & 4, blk - b0 - b1, b2);
 }
 
 template <typename F>
@@ -1986,20 +1990,20 @@ int sur_encoder_backward_multi(void* stream, int njobs, const sur_encoder_params
     }, "enc_bwd_multi");
 }
 
-int sur_flush_encoder_grads(void* stream, const sur_encoder_params* p, const sur_adam* adam) {
+int sur_flush_encoder_grads(void* stream, const sur_encoder_params* p, const sur_adam* adam, int overwrite) {
     if (!p || !p->partial) return fail(-1, "sur_flush_encoder_grads: bad argument");
     for (int i = 0; i < SUR_ENC_NPARAM; ++i)
         if (!p->g[i]) return fail(-1, "sur_flush_encoder_grads: gradient tensor %d is NULL", i);
     const int psize = psize_of<SUR_ENC_NPARAM>(p->size);
     sur_adam ad{};
     if (adam) {
-        if (!adam->m || !adam->v || !adam->step || !adam->ticket || !(adam->lr > 0.0f))
+        if (!adam->m || !adam->v || !adam->step || !adam->ticket || !adam->lr)
             return fail(-1, "flush: incomplete Adam descriptor");
         ad = *adam;
     }
     return launch_checked([&] {
         hipLaunchKernelGGL((flush_grads_kernel<SUR_ENC_NPARAM, sur_encoder_params>), dim3((psize + 31) / 32), dim3(TPB), 0,
-                           (hipStream_t)stream, *p, psize, ad);
+                           (hipStream_t)stream, *p, psize, ad, overwrite);
     }, "flush_enc");
 }
 
@@ -2135,25 +2139,25 @@ int sur_chunks_backward(void* stream, const sur_chunk_params* p, int nspans, con
                                 nullptr, row_base, row_count, saved, workspace, "sur_chunks_backward");
 }
 
-int sur_flush_chunk_grads(void* stream, const sur_chunk_params* p, const sur_adam* adam) {
+int sur_flush_chunk_grads(void* stream, const sur_chunk_params* p, const sur_adam* adam, int overwrite) {
     if (!p || !p->partial) return fail(-1, "sur_flush_chunk_grads: bad argument");
     for (int i = 0; i < SUR_ST_NPARAM; ++i)
         if (!p->g[i]) return fail(-1, "sur_flush_chunk_grads: gradient tensor %d is NULL", i);
     const int psize = psize_of<SUR_ST_NPARAM>(p->size);
     sur_adam ad{};
     if (adam) {
-        if (!adam->m || !adam->v || !adam->step || !adam->ticket || !(adam->lr > 0.0f))
+        if (!adam->m || !adam->v || !adam->step || !adam->ticket || !adam->lr)
             return fail(-1, "flush: incomplete Adam descriptor");
         ad = *adam;
     }
     return launch_checked([&] {
         hipLaunchKernelGGL((flush_grads_kernel<SUR_ST_NPARAM, sur_chunk_params>), dim3((psize + 31) / 32), dim3(TPB), 0,
-                           (hipStream_t)stream, *p, psize, ad);
+                           (hipStream_t)stream, *p, psize, ad, overwrite);
     }, "flush_chunk");
 }
 
 int sur_flush_all_grads(void* stream, const sur_encoder_params* e0, const sur_adam* a0, const sur_encoder_params* e1,
-                        const sur_adam* a1, const sur_chunk_params* c2, const sur_adam* a2) {
+                        const sur_adam* a1, const sur_chunk_params* c2, const sur_adam* a2, int overwrite_mask) {
     if (!e0 || !e1 || !c2 || !e0->partial || !e1->partial || !c2->partial) return fail(-1, "sur_flush_all_grads: bad argument");
     for (int i = 0; i < SUR_ENC_NPARAM; ++i)
         if (!e0->g[i] || !e1->g[i]) return fail(-1, "sur_flush_all_grads: encoder gradient tensor %d is NULL", i);
@@ -2163,7 +2167,7 @@ int sur_flush_all_grads(void* stream, const sur_encoder_params* e0, const sur_ad
     sur_adam ad[3] = {};
     for (int j = 0; j < 3; ++j)
         if (in[j]) {
-            if (!in[j]->m || !in[j]->v || !in[j]->step || !in[j]->ticket || !(in[j]->lr > 0.0f))
+            if (!in[j]->m || !in[j]->v || !in[j]->step || !in[j]->ticket || !in[j]->lr)
                 return fail(-1, "sur_flush_all_grads: incomplete Adam descriptor %d", j);
             ad[j] = *in[j];
         }
@@ -2171,7 +2175,7 @@ int sur_flush_all_grads(void* stream, const sur_encoder_params* e0, const sur_ad
     const int grid = (n0 + 31) / 32 + (n1 + 31) / 32 + (n2 + 31) / 32;
     return launch_checked([&] {
         hipLaunchKernelGGL(flush_all_kernel, dim3(grid), dim3(TPB), 0, (hipStream_t)stream, *e0, ad[0], n0, *e1, ad[1], n1, *c2, ad[2],
-                           n2);
+                           n2, overwrite_mask);
     }, "flush_all");
 }
 

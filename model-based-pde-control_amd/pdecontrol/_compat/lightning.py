@@ -16,9 +16,27 @@ except ImportError:
     from torch import nn
 
     class LightningModule(nn.Module):
+        automatic_optimization = True
+
         def __init__(self):
             super().__init__()
             self.logged = {}
+
+        # what a module under manual optimization asks its trainer for (pytorch-lightning 1.7 API)
+        def optimizers(self):
+            opts = self.__dict__.get("_shim_optimizers")
+            if not opts:
+                raise RuntimeError("no trainer attached")
+            return opts[0] if len(opts) == 1 else opts
+
+        def lr_schedulers(self):
+            scheds = self.__dict__.get("_shim_schedulers")
+            if not scheds:
+                return None
+            return scheds[0] if len(scheds) == 1 else scheds
+
+        def on_train_epoch_end(self):
+            pass
 
         def log(self, name, value, *args, **kwargs):
             self.logged[name] = value.detach() if isinstance(value, torch.Tensor) else value
@@ -44,21 +62,30 @@ except ImportError:
             loader = train_dataloaders if train_dataloaders is not None else datamodule.train_dataloader()
             optimizers, schedulers = module.configure_optimizers()
             opt = optimizers[0]
+            module.__dict__["_shim_optimizers"] = list(optimizers)
+            module.__dict__["_shim_schedulers"] = [s["scheduler"] for s in schedulers]
             module.train()
+            manual = not getattr(module, "automatic_optimization", True)
             for _ in range(self.max_epochs):
                 for bidx, batch in enumerate(loader):
                     if 0 <= self.max_steps <= self.global_step:
                         return
-                    opt.zero_grad(set_to_none=True)
-                    out = module.training_step(batch, bidx)
-                    out["loss"].backward()
-                    if self.gradient_clip_val:
-                        nn.utils.clip_grad_norm_(module.parameters(), self.gradient_clip_val)
-                    opt.step()
+                    if manual:      # the module owns backward + optimizer step (pl manual optimization)
+                        module.training_step(batch, bidx)
+                    else:           # pl's closure order: training_step -> zero_grad -> backward -> step
+                        out = module.training_step(batch, bidx)
+                        opt.zero_grad(set_to_none=True)
+                        out["loss"].backward()
+                        if self.gradient_clip_val:
+                            nn.utils.clip_grad_norm_(module.parameters(), self.gradient_clip_val)
+                        opt.step()
                     self.global_step += 1
                     self.callback_metrics.update(getattr(module, "logged", {}))
-                for s in schedulers:
-                    s["scheduler"].step()
+                if manual:
+                    module.on_train_epoch_end()
+                else:
+                    for s in schedulers:
+                        s["scheduler"].step()
 
     pl = types.SimpleNamespace(LightningModule=LightningModule, LightningDataModule=LightningDataModule,
                                Callback=Callback, Trainer=Trainer,

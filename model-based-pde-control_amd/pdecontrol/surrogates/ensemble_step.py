@@ -21,7 +21,7 @@ from typing import Sequence
 import torch
 
 from pdecontrol.surrogates import hipops
-from pdecontrol.surrogates.graph_step import GraphedTBPTTStep
+from pdecontrol.surrogates.graph_step import GraphedTBPTTStep, capture_graph
 
 
 class EnsembleTBPTTStep:
@@ -34,19 +34,26 @@ class EnsembleTBPTTStep:
             self.device = self.members[0].device
             assert all(g.device == self.device for g in self.members), "ensemble members must share one GPU"
             # member 0 stays on the capture stream, the others are its siblings
-            self.streams = [torch.cuda.Stream(device=self.device) for _ in self.members[1:]]
+            self.streams = hipops.pooled_streams(self.device, len(self.members) - 1, "member")
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            self.stream = self.members[0].stream
+
+            def record():
                 cur = torch.cuda.current_stream(self.device)
                 for st in self.streams:
                     st.wait_stream(cur)                      # fork
                 for g, st in zip(self.members, [cur] + self.streams):
                     with torch.cuda.stream(st), g.capturing():
                         g.result = g._fwd_bwd()
-                        if not g.adam_in_flush:
-                            g.opt.step()
+                    if not g.adam_in_flush:
+                        with torch.cuda.stream(st):
+                            g.shared.opt.step()
                 for st in self.streams:
                     cur.wait_stream(st)                      # join
+
+            capture_graph(self.graph, record, self.stream)
+            for g in self.members:
+                g.logged = dict(g.module.__dict__.pop("_graph_logged", {}))
 
     def __len__(self):
         return len(self.members)

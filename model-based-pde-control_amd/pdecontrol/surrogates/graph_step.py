@@ -10,19 +10,110 @@ Single GPU : [ zero grads | forward | backward | Adam ]                       = 
              gradient rows apply the Adam update themselves, and nothing needs zeroing)
 Data parallel: [ zero | forward | backward ] -> all-reduce(flat bucket) -> [ Adam ]  = two graphs with one
              RCCL call between them (pdecontrol.surrogates.distributed.FlatGradBucket).
+
+What is shared and what is per batch shape: a graph is tied to its static input buffers, so there is one
+``GraphedTBPTTStep`` per (states, actions) shape; the OPTIMIZER is tied to the parameters, so every step object of the
+same module uses the same Adam moments / step counter / learning rate (``_SharedTrainState``) -- a ragged last batch or
+a curriculum change of T continues the same optimisation, like the reference's single ``torch.optim.Adam``
+(pdecontrol/surrogates/training.py:273-278).
+
+Capture hygiene (the round-1 SIGABRT): torch >= 2.9 no longer runs ``gc.collect()`` when a capture starts.  If
+Python's cyclic collector fires INSIDE the capture and frees GPU objects of earlier work (graphs, events, tensors with
+recorded stream uses), their destructors issue HIP calls that are illegal while a stream is capturing and the
+process aborts.  ``capture_graph`` therefore collects before the capture and keeps the collector off during it;
+warm-up and capture run on the same explicit stream, and only detached tensors are kept from the captured step.
 """
+import gc
+
 import torch
 
 from pdecontrol.surrogates.distributed import FlatGradBucket
 
 
+def capture_graph(graph, fn, stream):
+    """Record ``fn()`` into ``graph`` on ``stream`` with the cyclic garbage collector parked (see module docstring)."""
+    gc.collect()
+    torch.cuda.synchronize(stream.device)
+    was_enabled = gc.isenabled()
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph, stream=stream):
+            out = fn()
+    finally:
+        if was_enabled:
+            gc.enable()
+    return out
+
+
+def _detached(result):
+    return {k: (v.detach() if isinstance(v, torch.Tensor) else v) for k, v in result.items()}
+
+
+class _SharedTrainState:
+    """Per-module state every captured step shares: the flat gradient bucket (param.grad are views of it), the
+    warm-up / capture stream, the torch Adam of the paths that do not fold the update into the flush launch, and the
+    learning rate."""
+
+    def __init__(self, module, lr):
+        params = list(module.surrogate.parameters())
+        self.device = params[0].device
+        self.bucket = FlatGradBucket(params)
+        from pdecontrol.surrogates.hipops import pooled_streams
+        (self.stream,) = pooled_streams(self.device, 1, "capture")
+        self.lr = float(lr)
+        self._params = params
+        self.opt = None
+
+    def torch_adam(self):
+        """Adam as ONE multi-tensor kernel, capturable, learning rate in a device scalar; state created (zeroed) here so
+        that a capture never allocates it."""
+        if self.opt is not None:
+            return self.opt
+        lr = torch.tensor(self.lr, device=self.device, dtype=torch.float32)
+        try:
+            opt = torch.optim.Adam(self._params, lr=lr, capturable=True, fused=True)
+        except (RuntimeError, TypeError, ValueError):
+            opt = torch.optim.Adam(self._params, lr=lr, capturable=True)
+        snap = [p.detach().clone() for p in self._params]
+        self.bucket.zero_()
+        opt.step()
+        with torch.no_grad():
+            for p, s in zip(self._params, snap):
+                p.copy_(s)
+            for st in opt.state.values():
+                st["step"].zero_()
+                st["exp_avg"].zero_()
+                st["exp_avg_sq"].zero_()
+        self.opt = opt
+        return opt
+
+    def set_lr(self, lr, packs=None):
+        lr = float(lr)
+        if packs is not None:
+            packs.set_lr(lr)
+        if lr != self.lr and self.opt is not None:
+            for group in self.opt.param_groups:
+                group["lr"].fill_(lr)
+        self.lr = lr
+
+
+def shared_state(module, lr=None):
+    state = module.__dict__.get("_graph_state")
+    first = next(module.surrogate.parameters())
+    if state is None or state.device != first.device or state._params[0] is not first:
+        state = _SharedTrainState(module, module.lr if lr is None else lr)
+        module.__dict__["_graph_state"] = state
+    elif lr is not None:
+        state.set_lr(lr, getattr(module.surrogate, "_fused_packs", None))
+    return state
+
+
 class GraphedTBPTTStep:
-    """``step()`` replays one optimizer step.  On the fused kernels (single GPU) the Adam update is part of the captured
-    gradient-reduction launches: ``self.opt`` then only documents the hyper-parameters, its state is not advanced."""
+    """``step()`` replays one optimizer step of ``module`` for one batch shape."""
 
     def __init__(self, module, batch_shape, action_shape=None, lr=None, distributed=False, warmup=3, capture=True):
         """module: PDETrainingModule on a CUDA device; batch_shape: [B, T, 1, N] of states.
-        capture=False prepares everything (static buffers, warmed-up kernels, fresh Adam state) but leaves
+        capture=False prepares everything (static buffers, warmed-up kernels, optimizer state) but leaves
         the capture to the caller (EnsembleTBPTTStep records several members into one graph)."""
         self.module = module
         dev = next(module.surrogate.parameters()).device
@@ -34,108 +125,94 @@ class GraphedTBPTTStep:
         self.states = tm(tuple(batch_shape))
         self.actions = tm(tuple(action_shape or batch_shape))
         self.distributed = distributed
-        self.bucket = FlatGradBucket(module.surrogate.parameters())
-        self.lr = lr if lr is not None else module.lr
-        self.opt = self._make_adam()
+        self.shared = shared_state(module, lr)
+        self.bucket = self.shared.bucket
+        self.stream = self.shared.stream
         self.result = None
         self.g_main = self.g_opt = None
         self.adam_in_flush = False
+        self._adam_state = None
+        self.logged = {}
         self._prepare(warmup)
         if capture:
             self._capture()
 
-    def _make_adam(self):
-        """Adam as ONE multi-tensor kernel (fused=True) instead of ~3 tiny kernels per parameter."""
-        params = list(self.module.surrogate.parameters())
-        try:
-            return torch.optim.Adam(params, lr=self.lr, capturable=True, fused=True)
-        except (RuntimeError, TypeError, ValueError):
-            return torch.optim.Adam(params, lr=self.lr, capturable=True)
+    @property
+    def lr(self):
+        return self.shared.lr
+
+    @property
+    def opt(self):
+        """The torch optimizer of the paths that need one (plain torch kernels, data-parallel); None when the Adam update
+        lives in the captured flush launches."""
+        return None if self.adam_in_flush else self.shared.torch_adam()
+
+    def _fused(self):
+        from pdecontrol.surrogates import ops
+        return ops.use_fused(self.states)
 
     def _fwd_bwd(self):
         if not self.adam_in_flush:
             self.bucket.zero_()
-        out = self.module.training_step((self.states, self.actions), 0)
-        from pdecontrol.surrogates import hipops, ops
-        if ops.fused_enabled():
+        out = self.module._eager_training_step((self.states, self.actions), 0)
+        if self._fused():
+            from pdecontrol.surrogates import hipops
             out["loss"].backward(gradient=hipops.unit_grad(self.device))
         else:
             out["loss"].backward()
-        return out
+        return _detached(out)
 
     def _prepare(self, warmup):
-        side = torch.cuda.Stream(device=self.device)
-        side.wait_stream(torch.cuda.current_stream(self.device))
-        # warm-up on a side stream with the real optimizer state untouched: snapshot and restore
-        snap = [p.detach().clone() for p in self.module.surrogate.parameters()]
-        with torch.cuda.stream(side):
+        """Warm the kernels / allocator on the capture stream.  Parameters and optimizer state are left untouched:
+        warm-up passes only compute gradients."""
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self.stream):
             for _ in range(warmup):
                 self._fwd_bwd()
-                self.opt.step()
-        torch.cuda.current_stream(self.device).wait_stream(side)
-        with torch.no_grad():
-            for p, s in zip(self.module.surrogate.parameters(), snap):
-                p.copy_(s)
-        self.opt = self._make_adam()
-        # Adam state must exist before capture: one throw-away step on zero grads, then reset
-        self.bucket.zero_()
-        self.opt.step()
-        with torch.no_grad():
-            for p, s in zip(self.module.surrogate.parameters(), snap):
-                p.copy_(s)
-            for st in self.opt.state.values():
-                st["step"].zero_()
-                st["exp_avg"].zero_()
-                st["exp_avg_sq"].zero_()
-        # fused kernels, single GPU: the flush launches take the Adam step (fresh state, like self.opt's)
-        # (the descriptors -- moment buffers, step counter -- are created here and handed to the packs only while
-        #  the graph is being captured: the captured launches carry them by value, and any other backward pass
-        #  through the same surrogate keeps accumulating plain gradients)
-        packs = getattr(self.module.surrogate, "_fused_packs", None)
-        from pdecontrol.surrogates import ops
-        if packs is not None and ops.fused_enabled() and not self.distributed:
-            betas, eps = self.opt.defaults["betas"], self.opt.defaults["eps"]
-            packs.enable_adam(self.lr, betas, eps)
-            self._adam_state = [pack.adam for pack in packs.packs]
-            packs.disable_adam()
-            self.adam_in_flush = True
+            packs = getattr(self.module.surrogate, "_fused_packs", None)
+            if packs is not None and self._fused() and not self.distributed:
+                # fused kernels, single GPU: the flush launches take the Adam step.  The descriptors (the surrogate's
+                # ONE set of moments / step counter / device learning rate) are lent to the packs only while a graph is
+                # being captured: the captured launches carry them by value, and any other backward pass through the
+                # same surrogate keeps accumulating plain gradients.
+                betas, eps = (0.9, 0.999), 1e-8
+                self._adam_state = packs.adam_descriptors(self.shared.lr, betas, eps)
+                self.adam_in_flush = True
+            else:
+                self.shared.torch_adam()
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
         torch.cuda.synchronize(self.device)
 
     def capturing(self):
         """Context manager for the duration of a hipGraph capture of ``_fwd_bwd``: lends the Adam descriptors to the
         surrogate's packs (no-op unless the optimizer step lives in the flush launches)."""
-        step = self
-
-        class _Lend:
-            def __enter__(self_inner):
-                if step.adam_in_flush:
-                    for pack, state in zip(step.module.surrogate._fused_packs.packs, step._adam_state):
-                        pack.adam = state
-
-            def __exit__(self_inner, *exc):
-                if step.adam_in_flush:
-                    step.module.surrogate._fused_packs.disable_adam()
-
-        return _Lend()
+        return _LendAdam(self)
 
     def _capture(self):
         self.g_main = torch.cuda.CUDAGraph()
-        if not self.distributed:
-            with self.capturing(), torch.cuda.graph(self.g_main):
-                self.result = self._fwd_bwd()
-                if not self.adam_in_flush:
-                    self.opt.step()
-            self.g_opt = None
-        else:
-            with torch.cuda.graph(self.g_main):
-                self.result = self._fwd_bwd()
-            self.g_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_opt):
-                self.opt.step()
 
-    def step(self, states=None, actions=None):
+        def main():
+            with self.capturing():
+                res = self._fwd_bwd()
+            if not self.adam_in_flush and not self.distributed:
+                self.shared.opt.step()
+            return res
+
+        self.result = capture_graph(self.g_main, main, self.stream)
+        # training_step's logged metrics of THIS captured step (static tensors, refreshed by every replay)
+        self.logged = dict(self.module.__dict__.pop("_graph_logged", {}))
+        if self.distributed:
+            self.g_opt = torch.cuda.CUDAGraph()
+            capture_graph(self.g_opt, self.shared.opt.step, self.stream)
+
+    def set_lr(self, lr):
+        self.shared.set_lr(lr, getattr(self.module.surrogate, "_fused_packs", None))
+
+    def step(self, states=None, actions=None, lr=None):
         """Copy the batch into the static buffers (if given) and replay.  Returns the static
-        result dict of training_step (tensors are overwritten by the next replay)."""
+        result dict of training_step (detached tensors, overwritten by the next replay)."""
+        if lr is not None:
+            self.set_lr(lr)
         if states is not None:
             self.states.copy_(states, non_blocking=True)
         if actions is not None:
@@ -145,3 +222,16 @@ class GraphedTBPTTStep:
             self.bucket.all_reduce_mean()
             self.g_opt.replay()
         return self.result
+
+
+class _LendAdam:
+    def __init__(self, step):
+        self.step = step
+
+    def __enter__(self):
+        if self.step.adam_in_flush:
+            self.step.module.surrogate._fused_packs.lend_adam(self.step._adam_state)
+
+    def __exit__(self, *exc):
+        if self.step.adam_in_flush:
+            self.step.module.surrogate._fused_packs.disable_adam()

@@ -39,7 +39,7 @@ class ChunkParams(ctypes.Structure):
 
 
 class AdamParams(ctypes.Structure):
-    _fields_ = [("m", _fp), ("v", _fp), ("step", _fp), ("ticket", _fp), ("lr", ctypes.c_float), ("beta1", ctypes.c_float),
+    _fields_ = [("m", _fp), ("v", _fp), ("step", _fp), ("ticket", _fp), ("lr", _fp), ("beta1", ctypes.c_float),
                 ("beta2", ctypes.c_float), ("eps", ctypes.c_float)]
 
 
@@ -61,15 +61,15 @@ SYMBOLS = (
     ("sur_encoder_backward_multi", [_fp, _i, ctypes.POINTER(_EP), ctypes.POINTER(_fp), ctypes.POINTER(_fp),
                                     ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_fp),
                                     ctypes.POINTER(_fp)]),
-    ("sur_flush_encoder_grads", [_fp, _EP, _AP]),
+    ("sur_flush_encoder_grads", [_fp, _EP, _AP, _i]),
     ("sur_chunk_saved_floats", [_CP]),
     ("sur_chunk_forward", [_fp, _CP, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _fp]),
     ("sur_chunk_workspace_floats", [_CP, _i, _i]),
     ("sur_chunk_backward", [_fp, _CP, _fp, _fp, _fp, _fp, _i, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _fp, _fp, _fp, _fp,
                             _i, _i, _fp, _fp]),
     ("sur_chunks_backward", [_fp, _CP, _i, ctypes.POINTER(ChunkSpan), _fp, _fp, _fp, _fp, _i, _i, _fp, _i, _i, _fp, _fp]),
-    ("sur_flush_chunk_grads", [_fp, _CP, _AP]),
-    ("sur_flush_all_grads", [_fp, _EP, _AP, _EP, _AP, _CP, _AP]),
+    ("sur_flush_chunk_grads", [_fp, _CP, _AP, _i]),
+    ("sur_flush_all_grads", [_fp, _EP, _AP, _EP, _AP, _CP, _AP, _i]),
     ("sur_tbptt_delta_loss", [_fp, _fp, ctypes.c_long, ctypes.c_long, _fp, _i, _i, _i, ctypes.c_float, ctypes.c_float, ctypes.c_float, _fp, _fp, _fp, _fp,
                               _fp, _fp, _fp]),
 )
@@ -111,16 +111,20 @@ def _p(t):
 # ---------------------------------------------------------------------------------------------
 # parameter packs
 # ---------------------------------------------------------------------------------------------
-def _grad_of(p):
-    if p.grad is None:
-        p.grad = torch.zeros_like(p)
-    return p.grad
-
-
 class _Pack:
     """Pointers to the weights / gradient tensors of one module in the kernel's order, plus the
     [rows][sum(size)] partial-gradient buffer the backward kernels accumulate into.  ``dirty`` is set
-    by a backward launch and cleared by ``flush`` (the reduction of the rows into ``param.grad``)."""
+    by a backward launch and cleared by ``flush`` (the reduction of the rows into ``param.grad``).
+
+    Lifetime rules (each one a bug once):
+      * gradient tensors are resolved when the flush is QUEUED, not during the forward pass: the caller may run
+        ``optimizer.zero_grad(set_to_none=True)`` between forward and backward (pytorch-lightning's closure does);
+      * when every ``param.grad`` is undefined the flush writes (g = sum) into a pack-owned flat buffer and hands out
+        views of it -- no zero-fill, no allocation per step;
+      * a partial buffer that has been superseded by a larger one is kept alive: captured hipGraphs (and launches
+        still in flight on side streams) carry its address by value and keep using it consistently;
+      * the Adam moments / step counter belong to the parameter set, not to a captured graph: every graph (one per
+        batch shape) of the same surrogate is lent the same descriptor."""
 
     def __init__(self, params, cstruct, flush_fn, rows):
         self.params, self.c, self._flush_fn = params, cstruct, flush_fn
@@ -128,37 +132,78 @@ class _Pack:
             self.c.size[i] = p.numel()
         self.psize = sum(p.numel() for p in params)
         self.partial = None
+        self._retired = []
         self.dirty = False
-        self.adam = None          # (AdamParams, tensors kept alive) when the optimizer step runs inside the flush
+        self.gflat, self._gviews = None, None
+        self.overwrite = False    # decided by resolve_grads() for the next flush
+        self._adam_state = None   # persistent (m, v, step, ticket)
+        self.adam = None          # (AdamParams, tensors kept alive) while the optimizer step runs inside the flush
         self.ensure_rows(rows)
         self.refresh()
 
     def ensure_rows(self, rows):
         if self.partial is None or self.partial.shape[0] < rows:
             assert not self.dirty, "cannot grow the partial-gradient buffer with unflushed gradients"
+            if self.partial is not None:
+                self._retired.append(self.partial)   # addresses baked into captured graphs stay valid (and zeroed)
+                rows = max(rows, (3 * self.partial.shape[0]) // 2)
+            rows = (rows + 127) // 128 * 128
             self.partial = torch.zeros((rows, self.psize), device=self.params[0].device, dtype=torch.float32)
-            self.c.partial, self.c.rows = self.partial.data_ptr(), rows
+        self.c.partial, self.c.rows = self.partial.data_ptr(), self.partial.shape[0]
 
     def refresh(self):
+        """Weight addresses (forward pass)."""
         for i, p in enumerate(self.params):
             assert p.is_cuda and p.is_contiguous() and p.dtype == torch.float32
             self.c.w[i] = p.data_ptr()
-            self.c.g[i] = _grad_of(p).data_ptr()
+
+    def resolve_grads(self):
+        """Gradient addresses, taken when the reduction is about to be launched.  Sets ``self.overwrite``."""
+        grads = [p.grad for p in self.params]
+        if all(g is None for g in grads):
+            if self.gflat is None:
+                self.gflat = torch.empty(self.psize, device=self.params[0].device, dtype=torch.float32)
+                self._gviews, off = [], 0
+                for p in self.params:
+                    self._gviews.append(self.gflat[off:off + p.numel()].view_as(p))
+                    off += p.numel()
+            for i, (p, view) in enumerate(zip(self.params, self._gviews)):
+                p.grad = view
+                self.c.g[i] = view.data_ptr()
+            self.overwrite = True
+            return
+        for i, (p, g) in enumerate(zip(self.params, grads)):
+            if g is None:
+                g = p.grad = torch.zeros_like(p)
+            if not (g.is_cuda and g.is_contiguous() and g.dtype == torch.float32):
+                raise SurrogateHipError("fused backward needs contiguous fp32 CUDA gradient tensors")
+            self.c.g[i] = g.data_ptr()
+        self.overwrite = False
 
     def flush(self):
         if self.dirty:
-            _check(self._flush_fn(_stream(), ctypes.byref(self.c), None if self.adam is None else ctypes.byref(self.adam[0])))
+            self.resolve_grads()
+            _check(self._flush_fn(_stream(), ctypes.byref(self.c), None if self.adam is None else ctypes.byref(self.adam[0]),
+                                  int(self.overwrite and self.adam is None)))
             self.dirty = False
 
-    def enable_adam(self, lr, betas=(0.9, 0.999), eps=1e-8):
-        """torch.optim.Adam(lr, betas, eps) applied by the flush launch itself (fresh moments, step 0)."""
-        dev = self.params[0].device
-        m = torch.zeros(self.psize, device=dev, dtype=torch.float32)
-        v = torch.zeros_like(m)
-        step = torch.zeros(1, device=dev, dtype=torch.int32)
-        ticket = torch.zeros(1, device=dev, dtype=torch.int32)
-        desc = AdamParams(m.data_ptr(), v.data_ptr(), step.data_ptr(), ticket.data_ptr(), lr, betas[0], betas[1], eps)
-        self.adam = (desc, m, v, step, ticket)
+    def adam_descriptor(self, lr_dev, betas=(0.9, 0.999), eps=1e-8):
+        """torch.optim.Adam(lr, betas, eps) applied by the flush launch itself.  The moments and the step counter are
+        created once per parameter set (zero moments, step 0) and shared by every descriptor handed out."""
+        if self._adam_state is None:
+            dev = self.params[0].device
+            m = torch.zeros(self.psize, device=dev, dtype=torch.float32)
+            self._adam_state = (m, torch.zeros_like(m), torch.zeros(1, device=dev, dtype=torch.int32),
+                                torch.zeros(1, device=dev, dtype=torch.int32))
+        m, v, step, ticket = self._adam_state
+        desc = AdamParams(m.data_ptr(), v.data_ptr(), step.data_ptr(), ticket.data_ptr(), lr_dev.data_ptr(), betas[0], betas[1],
+                          eps)
+        return (desc, m, v, step, ticket, lr_dev)
+
+    def reset_adam(self):
+        if self._adam_state is not None:
+            for t in self._adam_state:
+                t.zero_()
 
     def disable_adam(self):
         self.adam = None
@@ -173,9 +218,10 @@ CHUNK_ROWS = 384
 
 def _encoder_pack(convnet, n):
     from pdecontrol.surrogates.models.cnn import ResidualBlock
-    blocks = [getattr(convnet, name) for name in convnet.layers]
+    blocks = [getattr(convnet, name) for name in getattr(convnet, "layers", ())]
     if len(blocks) != 3 or not all(isinstance(b, ResidualBlock) for b in blocks):
-        raise SurrogateHipError("fused encoder expects three ResidualBlocks")
+        raise SurrogateHipError("fused encoder expects a ConvNet of three ResidualBlocks (KSAutoRegConvolutionalLSTM family); "
+                                "other architectures run on plain PyTorch-ROCm only after ops.enable_fused(False)")
     params, chans, strides = [], [blocks[0].conv3x3_l1.in_channels], []
     for b in blocks:
         if not isinstance(b.activation, nn.SiLU) or b.conv3x3_l1.kernel_size != (3,) or b.conv3x3_l1.bias is not None \
@@ -231,7 +277,7 @@ def _chunk_pack(surrogate, rows):
     if not isinstance(tm, CNNLSTMTransitionModel):
         raise SurrogateHipError("fused chunk expects a CNNLSTMTransitionModel")
     cell, dec = tm.cnnlstmcell, surrogate.state_decoder.model
-    blocks = [getattr(dec, name) for name in dec.layers]
+    blocks = [getattr(dec, name) for name in getattr(dec, "layers", ())]
     ok = (len(blocks) == 4 and isinstance(blocks[0], DeConvolutionBlock) and isinstance(blocks[1], DeConvolutionBlock)
           and isinstance(blocks[2], ConvBlock) and isinstance(blocks[3], ConvBlock)
           and blocks[2].convolution.kernel_size == (7,) and blocks[3].convolution.kernel_size == (5,)
@@ -267,8 +313,9 @@ class FusedPacks:
         self.anchor = torch.zeros((), device=dev, requires_grad=True)
         self.key = self._key(surrogate, n)
         self._flush_queued = False
-        self.side_streams = []
         self.loss_scratch = {}
+        self.lr_dev = torch.zeros(1, device=dev, dtype=torch.float32)   # Adam's learning rate, read by the flush launch
+        self._lr_host = None
 
     @staticmethod
     def _key(surrogate, n):
@@ -295,21 +342,44 @@ class FusedPacks:
         dirty = [pack for pack in self.packs if pack.dirty]
         if not dirty:
             return
+        for pack in dirty:
+            pack.resolve_grads()
         if len(dirty) == 3:   # the usual case: one launch reduces (and, with Adam enabled, applies) all three packs
             ad = lambda pack: None if pack.adam is None else ctypes.byref(pack.adam[0])
+            mask = sum((1 << j) for j, pack in enumerate(self.packs) if pack.overwrite and pack.adam is None)
             _check(load().sur_flush_all_grads(_stream(), ctypes.byref(self.state_enc.c), ad(self.state_enc),
                                               ctypes.byref(self.action_enc.c), ad(self.action_enc),
-                                              ctypes.byref(self.chunk.c), ad(self.chunk)))
+                                              ctypes.byref(self.chunk.c), ad(self.chunk), mask))
             for pack in dirty:
                 pack.dirty = False
             return
         for pack in dirty:
             pack.flush()
 
-    def enable_adam(self, lr, betas=(0.9, 0.999), eps=1e-8):
-        """Every flush of these packs also takes the Adam step of its parameters (hipops._Pack.enable_adam)."""
+    # -- optimizer inside the flush launches ---------------------------------------------------------------------
+    def set_lr(self, lr):
+        """Learning rate of the in-kernel Adam: a device scalar, so a scheduler can move it between graph replays."""
+        lr = float(lr)
+        if lr != self._lr_host:
+            self.lr_dev.fill_(lr)
+            self._lr_host = lr
+
+    def adam_descriptors(self, lr, betas=(0.9, 0.999), eps=1e-8):
+        """One descriptor per pack over the surrogate's ONE Adam state (created on first use)."""
+        self.set_lr(lr)
+        return [pack.adam_descriptor(self.lr_dev, betas, eps) for pack in self.packs]
+
+    def adam_step_count(self):
+        st = self.chunk._adam_state
+        return 0 if st is None else int(st[2].item())
+
+    def reset_adam(self):
         for pack in self.packs:
-            pack.enable_adam(lr, betas, eps)
+            pack.reset_adam()
+
+    def lend_adam(self, descriptors):
+        for pack, d in zip(self.packs, descriptors):
+            pack.adam = d
 
     def disable_adam(self):
         for pack in self.packs:
@@ -563,13 +633,25 @@ def fused_rollout(surrogate, states, actions, times, targets, hidden):
 # ---------------------------------------------------------------------------------------------
 # whole TBPTT forward/backward as ONE autograd node with hand-scheduled streams
 # ---------------------------------------------------------------------------------------------
-def _side_streams(owner, device, n):
-    """Side streams are owned by the surrogate's FusedPacks: two surrogates stepping concurrently (ensemble
-    members captured as parallel graph branches) must not meet on a shared stream."""
-    pool = owner.side_streams
+_STREAM_POOLS = {}
+
+
+def pooled_streams(device, n, kind="side"):
+    """The first ``n`` streams of a per-device, per-purpose pool that only ever grows.  torch hands out streams
+    round-robin from 32 per device, so code that creates a fresh ``torch.cuda.Stream`` per object eventually gets one
+    that aliases a stream it forks from or captures on; a handful of long-lived streams cannot.  Kinds in use:
+    "side" (forks inside one TBPTT step), "capture" (warm-up + hipGraph capture), "member" (ensemble siblings)."""
+    device = torch.device(device)
+    pool = _STREAM_POOLS.setdefault((device, kind), [])
     while len(pool) < n:
         pool.append(torch.cuda.Stream(device=device))
     return pool[:n]
+
+
+def _side_streams(owner, device, n):
+    """Side streams of one TBPTT step.  Steps of different surrogates never fork concurrently outside an ensemble
+    capture, and there the members keep to one stream each (``inner_forks(False)``), so the pool is shared."""
+    return pooled_streams(device, n, "side")
 
 
 _INNER_FORKS = True

@@ -1,40 +1,70 @@
 """Functional layer between the surrogate modules and the kernels that execute them.
 
 Every block of the surrogate goes through one of the functions below.  On CPU tensors they are
-plain torch (this is also the fp32 torch reference the HIP kernels are tested against); on CUDA
-tensors they use the hand-written gfx950 kernels of libsurrogate_hip.so when ``fused`` is enabled
-(``enable_fused(True)`` -- it raises if the library is missing, there is no silent fallback once
-fusion has been requested).
+plain torch (this is also the fp32 torch reference the HIP kernels are tested against).  On CUDA
+tensors the hand-written gfx950 kernels of libsurrogate_hip.so are THE path: they are on by default,
+the library's absence raises at the first CUDA tensor, and a surrogate whose geometry the kernels do
+not cover raises ``SurrogateHipError`` instead of quietly running PyTorch-ROCm / MIOpen kernels.  The
+plain torch-on-GPU path still exists as an explicit opt-out (``enable_fused(False)``, the
+``fused(False)`` context manager or ``PDECONTROL_FUSED=0``): it is the same-device cross-check of the
+parity tests and the "hipGraph over torch kernels" leg of the benchmark.
 """
 import os
 
 import torch
 
-# PDECONTROL_FUSED=1 selects the fused kernels without touching the caller's code (the reference's script.py runs
-# unmodified); the library is loaded at the first CUDA tensor and its absence raises there.
-_FUSED = {"enabled": os.environ.get("PDECONTROL_FUSED", "0") == "1", "lib": None}
+_DEFAULT = os.environ.get("PDECONTROL_FUSED", "1") != "0"
+_FUSED = {"enabled": _DEFAULT, "lib": None}
 
 
 def enable_fused(flag=True):
-    """Switch the CUDA code path to the fused HIP kernels (loads the library; raises if absent)."""
+    """Select the CUDA code path: True = fused HIP kernels (loads the library; raises if absent)."""
     if flag:
         from pdecontrol.surrogates import hipops
         _FUSED["lib"] = hipops.load()
     _FUSED["enabled"] = bool(flag)
 
 
+def reset_fused():
+    """Back to the process default (fused unless PDECONTROL_FUSED=0)."""
+    _FUSED["enabled"] = _DEFAULT
+
+
 def fused_enabled():
     return _FUSED["enabled"]
 
 
+class fused:
+    """``with ops.fused(False): ...`` -- run a block on the other CUDA path and restore the previous choice."""
+
+    def __init__(self, flag):
+        self.flag = bool(flag)
+
+    def __enter__(self):
+        self.prev = _FUSED["enabled"]
+        enable_fused(self.flag)
+        return self
+
+    def __exit__(self, *exc):
+        _FUSED["enabled"] = self.prev
+
+
 def use_fused(tensor):
-    """True when the fused HIP rollout (hipops.fused_rollout) should handle this tensor."""
+    """True when the fused HIP kernels handle this tensor (any CUDA tensor unless opted out)."""
     if not (_FUSED["enabled"] and tensor.is_cuda):
         return False
     if _FUSED["lib"] is None:
         from pdecontrol.surrogates import hipops
-        _FUSED["lib"] = hipops.load()
+        _FUSED["lib"] = hipops.load()   # raises when the library has not been built: no silent fallback
     return True
+
+
+def require_plain_path(tensor, what):
+    """Surrogates the fused kernels do not implement must not run on MIOpen by accident."""
+    if tensor.is_cuda and _FUSED["enabled"]:
+        from pdecontrol.surrogates.hipops import SurrogateHipError
+        raise SurrogateHipError(f"{what} has no fused HIP implementation; to run it on plain PyTorch-ROCm kernels opt out "
+                                f"explicitly with pdecontrol.surrogates.ops.enable_fused(False) or PDECONTROL_FUSED=0")
 
 
 def conv_act_norm(x, conv, activation, layernorm):

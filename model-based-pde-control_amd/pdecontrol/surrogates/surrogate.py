@@ -152,6 +152,7 @@ class LatentAutoRegPDESurrogate(_EncDecSurrogate):
 
     def rollout(self, states: torch.Tensor, actions: torch.Tensor, times: torch.Tensor, targets: torch.Tensor,
                 hidden=None, **kwargs) -> ModelRollout:
+        ops.require_plain_path(states, "LatentAutoRegPDESurrogate (ablation)")
         n_given = states.size(1)
         lstates = self.state_encoder(states)
         aidx, tidx = action_and_target_indices(times, targets, self.delta)

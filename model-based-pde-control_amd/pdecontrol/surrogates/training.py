@@ -8,7 +8,18 @@ names ("Train Loss", "Val. Loss", ...).
 What is different under the hood: logged values stay tensors (no ``.item()`` host sync inside
 the step), time grids are Python-side, and ``fused_step`` offers the whole
 forward + backward + Adam update as ONE replayable HIP graph for fixed batch shapes.
+
+How the reference's caller reaches the fast paths (``pl.Trainer.fit``, pdecontrol/mbrl/mbrl.py:593):
+  * default (automatic optimization): Lightning calls ``training_step`` eagerly, then ``backward`` and
+    ``optimizer.step``.  On a CUDA device ``training_step`` runs on the fused HIP kernels (21 launches) and
+    ``configure_optimizers`` returns a single-kernel (``fused=True``) Adam.
+  * ``graphed=True`` (constructor keyword, i.e. ``--training '{"initial": {"graphed": true, ...}}'`` through the
+    reference's own config channel, mbrl.py:230-245; or ``PDECONTROL_GRAPHED=1``): the module switches to Lightning's
+    manual optimization and ``training_step`` replays the captured graph (forward + backward + Adam in one
+    ``hipGraphLaunch``).  The optimizer returned by ``configure_optimizers`` then only carries the learning rate
+    (schedulers keep working: the graph reads it from a device scalar); its ``step`` is never called.
 """
+import os
 from typing import Callable
 
 import numpy as np
@@ -23,8 +34,11 @@ from pdegym.common.transforms import BatchTransform, Identity, SampleTransform
 class PDETrainingModule(pl.LightningModule):
     def __init__(self, surrogate: PDESurrogate, loss: Callable, tstep: float, delta: float, env=None,
                  stransf: SampleTransform = None, undscaling: BatchTransform = None, tau: int = 5, tbtt: int = 10,
-                 lr: float = 1e-03, lr_gamma: float = 1.0, step_size: int = 25, **kwargs):
+                 lr: float = 1e-03, lr_gamma: float = 1.0, step_size: int = 25, graphed: bool = None, **kwargs):
         super().__init__()
+        self.graphed = (os.environ.get("PDECONTROL_GRAPHED", "0") == "1") if graphed is None else bool(graphed)
+        if self.graphed:
+            self.automatic_optimization = False   # Lightning: training_step owns backward + optimizer step
         self.surrogate, self.loss, self.tstep, self.delta, self.env = surrogate, loss, tstep, delta, env
         self.stransf = SampleTransform() if stransf is None else stransf
         self.undscaling = BatchTransform(Identity()) if undscaling is None else undscaling
@@ -62,19 +76,22 @@ class PDETrainingModule(pl.LightningModule):
             return [out]
         rollouts = []
         seed_states, hidden = None, None
-        if isinstance(self.surrogate, AutoRegPDESurrogate):
+        autoreg = isinstance(self.surrogate, AutoRegPDESurrogate)
+        if autoreg:
             self.surrogate.reencode_predictions = False  # inlatents are never read by the loss
-        for c, achunk in enumerate(torch.split(actions, self.tbtt, dim=1)):
-            if c == 0:
-                seed_states = states[:, :self.tbtt][:, :self.tau]
-            times, targets = self._grid(achunk.size(1))
-            out = self.surrogate.rollout(states=seed_states, actions=achunk, times=times, targets=targets,
-                                         hidden=hidden)
-            rollouts.append(out)
-            seed_states = out.outputs[:, -1:].detach()
-            out.hidden = hidden = tuple(h.detach() for h in out.hidden)
-        if isinstance(self.surrogate, AutoRegPDESurrogate):
-            self.surrogate.reencode_predictions = True
+        try:
+            for c, achunk in enumerate(torch.split(actions, self.tbtt, dim=1)):
+                if c == 0:
+                    seed_states = states[:, :self.tbtt][:, :self.tau]
+                times, targets = self._grid(achunk.size(1))
+                out = self.surrogate.rollout(states=seed_states, actions=achunk, times=times, targets=targets,
+                                             hidden=hidden)
+                rollouts.append(out)
+                seed_states = out.outputs[:, -1:].detach()
+                out.hidden = hidden = tuple(h.detach() for h in out.hidden)
+        finally:
+            if autoreg:
+                self.surrogate.reencode_predictions = True
         return rollouts
 
     def _fused_delta_loss(self, rollouts, states):
@@ -92,6 +109,12 @@ class PDETrainingModule(pl.LightningModule):
         return hipops.fused_delta_loss(self.surrogate, d_all, states, self.delta, *consts)
 
     def training_step(self, batch, bidx):
+        states = batch[0]
+        if self.graphed and states.is_cuda:
+            return self._graphed_training_step(batch)
+        return self._eager_training_step(batch, bidx)
+
+    def _eager_training_step(self, batch, bidx):
         states, actions, *_ = batch
         rollouts = self.tbptt_forward(states, actions)
 
@@ -115,27 +138,59 @@ class PDETrainingModule(pl.LightningModule):
             m_out, s_out = outdeltas.detach().mean(), outdeltas.detach().std()
             m_true, s_true = deltas.detach().mean(), deltas.detach().std()
 
-        self.log("Train Loss", loss.detach(), on_step=False, on_epoch=True)
-        self.log("Train Mean Delta Output", m_out, on_step=False, on_epoch=True)
-        self.log("Train Std. Delta Output", s_out, on_step=False, on_epoch=True)
-        self.log("Train Mean Delta", m_true, on_step=False, on_epoch=True)
-        self.log("Train Std. Delta", s_true, on_step=False, on_epoch=True)
+        logged = {"Train Loss": loss.detach(), "Train Mean Delta Output": m_out.detach(), "Train Std. Delta Output": s_out.detach(),
+                  "Train Mean Delta": m_true.detach(), "Train Std. Delta": s_true.detach()}
+        if torch.cuda.is_available() and states.is_cuda and torch.cuda.is_current_stream_capturing():
+            self.__dict__["_graph_logged"] = logged     # static tensors of the captured step, logged at every replay
+        else:
+            for name, value in logged.items():
+                self.log(name, value, on_step=False, on_epoch=True)
 
         return {"loss": loss, "hsteploss": hsteploss.detach(), "outputs": outputs.detach(),
                 "actions": actions.detach(), "states": states.detach(), "outdeltas": outdeltas.detach(),
                 "deltas": deltas.detach()}
 
-    def fused_step(self, batch):
+    def fused_step(self, batch, lr=None):
         """One optimizer step -- training_step + backward + Adam(lr) -- as ONE replayed HIP graph on static
         buffers (pdecontrol.surrogates.graph_step.GraphedTBPTTStep; a graph per batch shape, captured on first
-        use).  Returns training_step's dict; its tensors are overwritten by the next call.  CUDA only."""
+        use; ONE Adam state and learning rate for all of them).  Returns training_step's dict; its tensors are
+        overwritten by the next call.  CUDA only."""
         from pdecontrol.surrogates.graph_step import GraphedTBPTTStep
         states, actions, *_ = batch
         key = (tuple(states.shape), tuple(actions.shape))
         cache = self.__dict__.setdefault("_graphed_steps", {})
         if key not in cache:
-            cache[key] = GraphedTBPTTStep(self, key[0], key[1])
-        return cache[key].step(states, actions)
+            cache[key] = GraphedTBPTTStep(self, key[0], key[1], lr=lr)
+        self.__dict__["_last_graphed_step"] = cache[key]
+        return cache[key].step(states, actions, lr=lr)
+
+    def _graphed_training_step(self, batch):
+        """training_step under Lightning's manual optimization: replay the graph with the learning rate of the
+        optimizer Lightning holds (so StepLR and friends act on the captured Adam), log what training_step logs."""
+        lr = None
+        try:
+            opts = self.optimizers()
+            opt = opts[0] if isinstance(opts, (list, tuple)) else opts
+            lr = float(opt.param_groups[0]["lr"])
+        except Exception:   # no trainer attached (direct call): the module's own lr
+            lr = None
+        out = self.fused_step(batch, lr=lr)
+        # the five "Train ..." metrics of the step that was just replayed (static tensors of that captured step)
+        for name, value in self.__dict__["_last_graphed_step"].logged.items():
+            self.log(name, value, on_step=False, on_epoch=True)
+        return out
+
+    def on_train_epoch_end(self):
+        # manual optimization: Lightning does not step the schedulers for us
+        if self.graphed:
+            try:
+                scheds = self.lr_schedulers()
+            except Exception:
+                return
+            if scheds is None:
+                return
+            for sch in (scheds if isinstance(scheds, (list, tuple)) else [scheds]):
+                sch.step()
 
     # -- validation / test: one un-truncated rollout ------------------------------------------
     def validation_step(self, batch, bidx):
@@ -206,6 +261,9 @@ class PDETrainingModule(pl.LightningModule):
         return data
 
     def configure_optimizers(self):
-        optimizer = torch.optim.Adam(self.surrogate.parameters(), lr=self.lr)
+        params = list(self.surrogate.parameters())
+        # same update rule as the reference's Adam; on a GPU as one multi-tensor kernel instead of ~6 per parameter
+        extra = {"fused": True} if params and params[0].is_cuda else {}
+        optimizer = torch.optim.Adam(params, lr=self.lr, **extra)
         scheduler = torch.optim.lr_scheduler.StepLR(optimizer, step_size=self.step_size, gamma=self.lr_gamma)
         return [optimizer], [{"scheduler": scheduler, "interval": "epoch"}]

@@ -295,7 +295,11 @@ def surrogate_fixtures(tr):
     gn = torch.sqrt(sum((p.grad ** 2).sum() for p in surrogate.parameters() if p.grad is not None))
     out["b64_loss"] = np.float64(res["loss"].item())
     out["b64_gradnorm"] = np.float64(gn.item())
+    out["b64_grad_norm"] = out["b64_gradnorm"]
     out["b64_hsteploss"] = res["hsteploss"].numpy().copy()
+    for k, p in surrogate.named_parameters():     # the benchmarked batch: per-parameter gradients too (39 KB)
+        if p.grad is not None:
+            out["b64_grad/" + k] = p.grad.numpy().copy()
 
     # (7b) B=8 slice with all tensors + per-parameter grads
     surrogate, module = build()
@@ -392,6 +396,85 @@ def surrogate_fixtures(tr):
     out["norm_count"] = np.int64(norm.count)
     out["norm_apply"] = norm(b1).numpy().copy()
     out["norm_inverse"] = norm.Inverse(b1).numpy().copy()
+    return out
+
+
+# --------------------------------------------------------------------------- #
+# N = 256 surrogate (BASELINE configs[2] / [3]): the reference's factory hard-codes N = 64
+# (pdecontrol/architectures/autoreg.py:60,72,93), its building blocks are size-parametric.  This builds the SAME
+# network from the reference's own classes -- ConvNet / ResidualBlock / (De)ConvolutionBlock (surrogates/models/cnn.py),
+# CNNLSTMTransitionModel (surrogates/transition.py:229-296), AutoRegPDESurrogate, PDETrainingModule -- with every
+# LayerNorm / latent width scaled by N / 64, in the factory's construction order (so a seed gives the same init stream).
+# --------------------------------------------------------------------------- #
+def surrogate_n256_fixtures():
+    from torch import nn
+    from pdecontrol.surrogates.models import cnn as CNN
+    from pdecontrol.surrogates.surrogate import AutoRegPDESurrogate
+    from pdecontrol.surrogates.training import PDETrainingModule
+    from pdecontrol.surrogates.transition import CNNLSTMTransitionModel
+    from pdegym.common.transforms import BatchTransform, Normalize
+
+    N = 256
+    half, quarter = N // 2, N // 4
+    out = {"N": np.int64(N)}
+
+    def encoder(channels):
+        return CNN.ConvNet(in_channels=1, blocks=[CNN.ResidualBlock] * 3, out_channels=channels, kernel_size=[3] * 3,
+                           stride=[2, 2, 1], activation=[nn.SiLU] * 3,
+                           layernorm=[nn.LayerNorm(half), nn.LayerNorm(quarter), nn.LayerNorm(quarter)])
+
+    def build(scaled):
+        torch.manual_seed(0)
+        state_encoder = encoder([8, 16, 16])
+        action_encoder = encoder([2, 4, 4])
+        transition_model = CNNLSTMTransitionModel(schannels=16, ssize=quarter, achannels=4, asize=quarter)
+        state_decoder = CNN.ConvNet(
+            in_channels=16, blocks=[CNN.DeConvolutionBlock, CNN.DeConvolutionBlock, CNN.ConvBlock, CNN.ConvBlock],
+            out_channels=[16, 8, 1, 1], kernel_size=[3, 3, 7, 5], stride=[2, 2, 1, 1], padding=[1, 1, 3, 2],
+            output_padding=[1, 1], activation=[nn.SiLU, nn.SiLU, nn.SiLU, nn.Identity],
+            layernorm=[nn.LayerNorm(half), nn.LayerNorm(N), nn.LayerNorm(N)])
+        und = None
+        if scaled:
+            norm = Normalize(aggregate=True, batched=True)
+            norm.mean, norm.var, norm.count = torch.full((1, 1, 1), 0.01), torch.full((1, 1, 1), 0.5), 100
+            und = BatchTransform(norm)
+        surrogate = AutoRegPDESurrogate(state_encoder=state_encoder, state_decoder=state_decoder,
+                                        action_encoder=action_encoder, transition_model=transition_model, delta=0.25,
+                                        dscaling=None if und is None else und.Inverse, tau=5)
+        module = PDETrainingModule(surrogate=surrogate, loss=nn.MSELoss(reduction="none"), tstep=0.25, delta=0.25,
+                                   undscaling=und, tau=5, tbtt=10)
+        return surrogate, module
+
+    surrogate, module = build(False)
+    for k, v in surrogate.state_dict().items():
+        out["sd/" + k] = v.numpy().copy()
+    out["n_trainable"] = np.int64(sum(p.numel() for p in surrogate.parameters() if p.requires_grad))
+    g = torch.Generator().manual_seed(1)
+    s64 = torch.rand(64, 20, 1, N, generator=g) * 2 - 1
+    a64 = torch.rand(64, 20, 1, N, generator=g) * 2 - 1
+    # the benchmarked batch (B = 64, T = 20, Normalize scaling): loss, per-step loss, gradients -- inputs are
+    # regenerated from the seed by the tests, not stored (2 x 1.3 MB)
+    surrogate, module = build(True)
+    res = module.training_step((s64, a64), 0)
+    res["loss"].backward()
+    out["b64n_loss"] = np.float64(res["loss"].item())
+    out["b64n_hsteploss"] = res["hsteploss"].numpy().copy()
+    for k, p in surrogate.named_parameters():
+        if p.grad is not None:
+            out["b64n_grad/" + k] = p.grad.numpy().copy()
+    # B = 4 with every tensor, identity and Normalize scaling
+    s4, a4 = s64[:4].clone(), a64[:4].clone()
+    for scaled, tag in ((False, "b4"), (True, "b4n")):
+        surrogate, module = build(scaled)
+        res = module.training_step((s4, a4), 0)
+        res["loss"].backward()
+        out[f"{tag}_loss"] = np.float64(res["loss"].item())
+        out[f"{tag}_hsteploss"] = res["hsteploss"].numpy().copy()
+        out[f"{tag}_outputs"] = res["outputs"].numpy().copy()
+        out[f"{tag}_outdeltas"] = res["outdeltas"].numpy().copy()
+        for k, p in surrogate.named_parameters():
+            if p.grad is not None:
+                out[f"{tag}_grad/" + k] = p.grad.numpy().copy()
     return out
 
 
@@ -511,7 +594,7 @@ def world_fixtures(ks):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-reset", action="store_true", help="skip the two ~50 s burn-in resets")
-    ap.add_argument("--only", choices=["ks", "surrogate", "wrappers", "dataset", "world"], default=None)
+    ap.add_argument("--only", choices=["ks", "surrogate", "surrogate256", "wrappers", "dataset", "world"], default=None)
     args = ap.parse_args()
     if not os.path.isdir(REF):
         sys.exit("reference not present: fixtures can only be generated in the build container")
@@ -527,6 +610,11 @@ def main():
         fx = surrogate_fixtures(tr)
         np.savez_compressed(os.path.join(OUT, "surrogate_golden.npz"), **fx)
         print("surrogate_golden.npz:", len(fx), "arrays")
+    if args.only in (None, "surrogate256"):
+        import pdecontrol.surrogates.training  # noqa: F401
+        fx = surrogate_n256_fixtures()
+        np.savez_compressed(os.path.join(OUT, "surrogate_n256_golden.npz"), **fx)
+        print("surrogate_n256_golden.npz:", len(fx), "arrays")
     if args.only in (None, "world"):
         ksm = _load("pdegym.kuramoto.kuramoto", "pdegym/kuramoto/kuramoto.py")
         fx = world_fixtures(ksm)

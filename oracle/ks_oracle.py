@@ -171,3 +171,32 @@ def step_scipy_structured(u, phi, dx, dt, n_substeps):
         k4 = f(u + dt * k3)
         u = u + dt * (k1 + 2.0 * k2 + 2.0 * k3 + k4) / 6.0
     return u, float(reward)
+
+
+def _structured_worker(argv):
+    """``python oracle/ks_oracle.py --structured-worker N L seconds seed``: one process of bench.py's baseline (A) --
+    one env, the reference's call structure, stepped for ~``seconds``.  Prints "ready" once imports and first calls
+    are done, starts when a line arrives on stdin (the parent releases all workers together)."""
+    import json
+    import sys
+    import time
+    N, L, seconds, seed = int(argv[0]), float(argv[1]), float(argv[2]), int(argv[3])
+    rs = np.random.RandomState(seed)
+    u = rs.uniform(-0.4, 0.4, N)
+    phi = (0.1 * rs.uniform(-1, 1, N)).astype(np.float32).astype(np.float64)
+    u, _ = step_scipy_structured(u, phi, L / N, 1e-3, 20)      # imports + first-call costs out of the timed loop
+    print("ready", flush=True)
+    sys.stdin.readline()
+    done, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        u, _ = step_scipy_structured(u, phi, L / N, 1e-3, 250)
+        done += 250
+    dt = time.perf_counter() - t0
+    assert np.isfinite(u).all()
+    print(json.dumps({"substeps": done, "seconds": dt}))
+
+
+if __name__ == "__main__":
+    import sys
+    if len(sys.argv) >= 6 and sys.argv[1] == "--structured-worker":
+        _structured_worker(sys.argv[2:])

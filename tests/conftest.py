@@ -28,3 +28,16 @@ def ks_golden():
 @pytest.fixture(scope="session")
 def sur_golden():
     return np.load(os.path.join(GOLDEN, "surrogate_golden.npz"))
+
+
+@pytest.fixture(autouse=True)
+def _default_cuda_path():
+    """Every test starts on the process default of the surrogate's CUDA path (fused HIP kernels)."""
+    try:
+        from pdecontrol.surrogates import ops
+    except ImportError:
+        yield
+        return
+    ops.reset_fused()
+    yield
+    ops.reset_fused()

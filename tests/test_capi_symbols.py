@@ -76,8 +76,8 @@ def test_surrogate_abi_rejects_bad_arguments_before_touching_the_device():
     assert lib.sur_encoder_backward_multi(null, 4, null, null, null, null, null, null, null, null) < 0
     assert b"sur_encoder_backward_multi" in lib.sur_last_error()
     assert lib.sur_chunks_backward(null, ctypes.byref(chunk), 9, null, null, null, null, null, 4, 4, null, 0, 16, null, null) < 0
-    assert lib.sur_flush_encoder_grads(null, ctypes.byref(enc), null) < 0      # no partial buffer
-    assert lib.sur_flush_chunk_grads(null, ctypes.byref(chunk), null) < 0
+    assert lib.sur_flush_encoder_grads(null, ctypes.byref(enc), null, 0) < 0      # no partial buffer
+    assert lib.sur_flush_chunk_grads(null, ctypes.byref(chunk), null, 0) < 0
     assert lib.sur_tbptt_delta_loss(null, null, 128, 64, null, 1, 2, 64, 0.25, 0.0, 1.0, null, null, null, null, null, null, null) < 0
     assert b"sur_tbptt_delta_loss" in lib.sur_last_error()
     # geometry queries are pure host functions

@@ -140,7 +140,6 @@ def test_fused_training_step_matches_unfused_and_golden(dev, sur_golden):
             _zero(m)
             res = m.training_step((s, a), 0)
             res["loss"].backward()
-            ops.enable_fused(False)
             rel = abs(res["loss"].item() - g[f"{tag}_loss"]) / abs(g[f"{tag}_loss"])
             assert rel < 1e-5, rel
             np.testing.assert_allclose(res["outputs"].cpu().numpy(), g[f"{tag}_outputs"], rtol=1e-3, atol=1e-4)
@@ -151,7 +150,7 @@ def test_fused_training_step_matches_unfused_and_golden(dev, sur_golden):
                     np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=1e-2,
                                                atol=3e-5 * max(1.0, np.abs(ref).max()), err_msg=k)
     finally:
-        ops.enable_fused(False)
+        ops.reset_fused()
 
 
 def test_fused_hip_graph_training_matches_unfused(dev):
@@ -159,14 +158,15 @@ def test_fused_hip_graph_training_matches_unfused(dev):
     from pdecontrol.surrogates.bench_tbptt import build_module, synthetic_batch
     from pdecontrol.surrogates.graph_step import GraphedTBPTTStep
     batch = synthetic_batch(B=16, device=dev)
-    plain = GraphedTBPTTStep(build_module(dev), tuple(batch[0].shape))
-    l_plain = [float(plain.step(*batch)["loss"].detach()) for _ in range(4)]
+    with ops.fused(False):
+        plain = GraphedTBPTTStep(build_module(dev), tuple(batch[0].shape))
+        l_plain = [float(plain.step(*batch)["loss"].detach()) for _ in range(4)]
     try:
         ops.enable_fused(True)
         fused = GraphedTBPTTStep(build_module(dev), tuple(batch[0].shape))
         l_fused = [float(fused.step(*batch)["loss"].detach()) for _ in range(4)]
     finally:
-        ops.enable_fused(False)
+        ops.reset_fused()
     np.testing.assert_allclose(l_fused, l_plain, rtol=3e-5)
     assert l_fused[-1] < l_fused[0]
 
@@ -204,7 +204,7 @@ def test_ensemble_parallel_step_equals_member_by_member(dev):
         assert ens_losses == seq_losses
         assert len({l[0] for l in ens_losses}) == 3  # members really are different models / batches
     finally:
-        ops.enable_fused(False)
+        ops.reset_fused()
 
 
 @pytest.mark.parametrize("N", [64, 256])
@@ -230,7 +230,7 @@ def test_encoder_saved_activations_backward_matches_recompute(dev, N, monkeypatc
                 f = hipops.load().sur_chunk_saved_floats(__import__("ctypes").byref(m.surrogate._fused_packs.chunk.c))
                 assert f > 0, "saved-activation path not available for this geometry"
     finally:
-        ops.enable_fused(False)
+        ops.reset_fused()
     assert losses[0] == losses[1]
     assert grads[0].keys() == grads[1].keys() and len(grads[0]) > 20
     for k in grads[0]:
@@ -257,7 +257,7 @@ def test_fused_delta_loss_matches_torch_ops(dev, scaled):
             torch.cuda.synchronize()
             res[mode] = (out, dict(m.logged), _grads(m))
     finally:
-        ops.enable_fused(False)
+        ops.reset_fused()
     (of, lf, gf), (ot, lt, gt) = res["fused_loss"], res["torch_loss"]
     assert of["loss"].shape == ot["loss"].shape == ()
     np.testing.assert_allclose(float(of["loss"].detach()), float(ot["loss"].detach()), rtol=2e-6)
@@ -298,7 +298,7 @@ def test_graphed_step_leaves_eager_backward_untouched(dev):
         stepped = torch.cat([p.detach().reshape(-1) for p in m.surrogate.parameters()])
         assert not torch.equal(stepped, after)
     finally:
-        ops.enable_fused(False)
+        ops.reset_fused()
 
 
 def test_adam_inside_the_flush_launch_matches_torch_adam(dev):
@@ -326,7 +326,7 @@ def test_adam_inside_the_flush_launch_matches_torch_adam(dev):
         for (name, p), q in zip(m.surrogate.named_parameters(), ref.surrogate.parameters()):
             np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), rtol=2e-5, atol=2e-7, err_msg=name)
     finally:
-        ops.enable_fused(False)
+        ops.reset_fused()
 
 
 @pytest.mark.parametrize("T", [12, 25, 45])
@@ -348,7 +348,7 @@ def test_fused_tbptt_other_chunkings(dev, T):
             torch.cuda.synchronize(dev)
             res[fused] = (out, _grads(m))
     finally:
-        ops.enable_fused(False)
+        ops.reset_fused()
     (ot, gt), (of, gf) = res[False], res[True]
     np.testing.assert_allclose(float(of["loss"].detach()), float(ot["loss"].detach()), rtol=1e-5)
     _close(of["outputs"], ot["outputs"], rtol=1e-3, atol_scale=1e-4, msg="outputs")

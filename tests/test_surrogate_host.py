@@ -1,5 +1,7 @@
 """Surrogate mirror (pdecontrol.*) on CPU against golden tensors captured from the reference.
 The CPU path is plain torch, i.e. the fp32 torch reference the GPU kernels are compared to."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -167,15 +169,95 @@ def test_tbtt_must_exceed_tau():
 
 
 def test_fused_path_env_switch(monkeypatch):
-    """PDECONTROL_FUSED=1 selects the fused kernels at import; CPU tensors never take that path."""
+    """The fused kernels are the default CUDA path; PDECONTROL_FUSED=0 opts out at import; CPU tensors never take it."""
     import importlib
     from pdecontrol.surrogates import ops
-    monkeypatch.setenv("PDECONTROL_FUSED", "1")
+    monkeypatch.setenv("PDECONTROL_FUSED", "0")
     try:
         importlib.reload(ops)
-        assert ops.fused_enabled()
-        assert not ops.use_fused(torch.zeros(2))      # CPU tensor: plain torch path, no library load
+        assert not ops.fused_enabled()
     finally:
         monkeypatch.delenv("PDECONTROL_FUSED")
         importlib.reload(ops)
-    assert not ops.fused_enabled()
+    assert ops.fused_enabled()
+    assert not ops.use_fused(torch.zeros(2))      # CPU tensor: plain torch path, no library load
+    with ops.fused(False):
+        assert not ops.fused_enabled()
+    assert ops.fused_enabled()
+
+
+def test_shim_trainer_follows_lightning_closure_order_and_manual_optimization():
+    """The in-repo Trainer drives training_step -> zero_grad -> backward -> step (pytorch-lightning's closure order) and,
+    for automatic_optimization = False, leaves everything to training_step."""
+    from pdecontrol._compat.lightning import IS_SHIM, pl
+    if not IS_SHIM:
+        pytest.skip("real pytorch-lightning present")
+    torch.manual_seed(0)
+    f = KSAutoRegConvolutionalLSTM()
+    s = f.surrogate(delta=0.25, dscaling=None, tau=5, **f.model())
+    m = PDETrainingModule(surrogate=s, loss=torch.nn.MSELoss(reduction="none"), tstep=0.25, delta=0.25, tau=5, tbtt=10)
+    gen = torch.Generator().manual_seed(3)
+    batch = (torch.rand(2, 12, 1, 64, generator=gen), torch.rand(2, 12, 1, 64, generator=gen))
+    before = torch.cat([p.detach().reshape(-1) for p in s.parameters()]).clone()
+    tr = pl.Trainer(max_steps=2, max_epochs=1)
+    tr.fit(m, train_dataloaders=[batch, batch, batch])
+    assert tr.global_step == 2 and "Train Loss" in tr.callback_metrics
+    after = torch.cat([p.detach().reshape(-1) for p in s.parameters()])
+    assert not torch.equal(before, after)
+    assert PDETrainingModule(surrogate=s, loss=torch.nn.MSELoss(reduction="none"), tstep=0.25, delta=0.25, tau=5, tbtt=10,
+                             graphed=True).automatic_optimization is False
+
+
+# ---- N = 256 (BASELINE configs[2] / [3]): KSAutoRegConvolutionalLSTMN against the reference's own building blocks ----
+N256_GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "surrogate_n256_golden.npz")
+
+
+def build_n256(scaled, device="cpu"):
+    """Same construction as oracle/gen_golden.py::surrogate_n256_fixtures, from this repo's classes."""
+    from pdecontrol.architectures import KSAutoRegConvolutionalLSTMN
+    from pdegym.common.transforms import BatchTransform, Normalize
+    torch.manual_seed(0)
+    f = KSAutoRegConvolutionalLSTMN()
+    model = f.model(N=256)
+    und = None
+    if scaled:
+        norm = Normalize(aggregate=True, batched=True)
+        norm.mean, norm.var, norm.count = torch.full((1, 1, 1), 0.01), torch.full((1, 1, 1), 0.5), 100
+        und = BatchTransform(norm)
+    s = f.surrogate(delta=0.25, dscaling=None if und is None else und.Inverse, tau=5, **model)
+    m = PDETrainingModule(surrogate=s, loss=torch.nn.MSELoss(reduction="none"), tstep=0.25, delta=0.25, undscaling=und,
+                          tau=5, tbtt=10)
+    return m.to(device)
+
+
+def n256_batch(B):
+    g = torch.Generator().manual_seed(1)
+    s = torch.rand(64, 20, 1, 256, generator=g) * 2 - 1
+    a = torch.rand(64, 20, 1, 256, generator=g) * 2 - 1
+    return s[:B].clone(), a[:B].clone()
+
+
+def test_n256_factory_matches_reference_building_blocks():
+    """state_dict (same seed -> same initial weights), parameter count, loss / outputs / gradients of a TBPTT step at
+    N = 256, identity and Normalize scaling, against tensors produced by the reference's ConvNet / ResidualBlock /
+    CNNLSTMTransitionModel / AutoRegPDESurrogate / PDETrainingModule classes (models/cnn.py:73-173,
+    transition.py:229-296) instantiated at N = 256."""
+    g = np.load(N256_GOLDEN)
+    m = build_n256(False)
+    sd = m.surrogate.state_dict()
+    keys = [k[3:] for k in g.files if k.startswith("sd/")]
+    assert sorted(sd.keys()) == sorted(keys)
+    for k in keys:
+        np.testing.assert_array_equal(sd[k].numpy(), g["sd/" + k], err_msg=k)
+    assert sum(p.numel() for p in m.surrogate.parameters() if p.requires_grad) == int(g["n_trainable"])
+    s4, a4 = n256_batch(4)
+    for scaled, tag in ((False, "b4"), (True, "b4n")):
+        m = build_n256(scaled)
+        res = m.training_step((s4, a4), 0)
+        res["loss"].backward()
+        assert res["loss"].item() == float(g[f"{tag}_loss"])
+        np.testing.assert_array_equal(res["outputs"].numpy(), g[f"{tag}_outputs"])
+        np.testing.assert_array_equal(res["outdeltas"].numpy(), g[f"{tag}_outdeltas"])
+        for k, p in m.surrogate.named_parameters():
+            if p.grad is not None:
+                np.testing.assert_allclose(p.grad.numpy(), g[f"{tag}_grad/" + k], rtol=1e-5, atol=1e-7, err_msg=k)
