@@ -57,7 +57,9 @@ typedef enum ks_variant {
     KS_VARIANT_WAVE64_DPP = 3, /* env = 64 lanes x N/64 points, halo by DPP wave_ror/rol:1    */
     KS_VARIANT_WAVE64_BPERM = 4,/* same layout, halo by ds_bpermute                           */
     KS_VARIANT_HALF32_BPERM = 5,/* env = 32 lanes x N/32 points, halo by ds_bpermute          */
-    KS_VARIANT_LDS = 6         /* one workgroup per env, state staged in LDS; any 9 <= N <= 2048 */
+    KS_VARIANT_LDS = 6,        /* one workgroup per env, state staged in LDS; any 9 <= N <= 2048 */
+    KS_VARIANT_WAVE64_HYBRID = 7, /* N = 64: env = one wavefront, halo +-1, +-2 by DPP wave_ror/rol, +-3, +-4 by ds_bpermute */
+    KS_VARIANT_WAVE64_HYBRID1 = 8 /* N = 64: halo +-1..+-3 by the DPP chain, +-4 by ds_bpermute */
 } ks_variant;
 
 /* ---- lifetime -------------------------------------------------------------------------- */

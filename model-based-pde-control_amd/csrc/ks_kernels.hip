@@ -27,7 +27,7 @@
 
 namespace ks {
 
-enum { HALO_BPERM = 0, HALO_DPP_ROW = 1, HALO_DPP_WAVE = 2 };
+enum { HALO_BPERM = 0, HALO_DPP_ROW = 1, HALO_DPP_WAVE = 2, HALO_HYBRID = 3, HALO_HYBRID1 = 4 };
 
 // ------------------------------------------------------------------------------------------
 // cross-lane primitives
@@ -106,6 +106,52 @@ struct Halo<64, HALO_DPP_WAVE> {
     static constexpr bool CHAIN = true;
     __device__ __forceinline__ double lower(int, double x) const { return wave_from_lower1(x); }
     __device__ __forceinline__ double upper(int, double x) const { return wave_from_upper1(x); }
+};
+
+// One point per lane (N = 64), hybrid: distances 1 and 2 by the DPP chain (4 + 4 VALU moves), distances 3 and 4 through
+// the LDS crossbar (8 ds_bpermute_b32: LDS-pipe instructions that cost no VALU issue slot and are in flight while the
+// near-neighbour terms are computed).  16 -> 8 VALU moves per RK stage against the pure DPP chain.
+template <>
+struct Halo<64, HALO_HYBRID> {
+    static constexpr bool CHAIN = false;
+    int lo3, lo4, up3, up4;
+    __device__ __forceinline__ Halo() {
+        const int lane = threadIdx.x & 63;
+        lo3 = ((lane - 3) & 63) << 2;
+        lo4 = ((lane - 4) & 63) << 2;
+        up3 = ((lane + 3) & 63) << 2;
+        up4 = ((lane + 4) & 63) << 2;
+    }
+    // generic accessors (self test, exact mode): x is always the lane's own value
+    __device__ __forceinline__ double lower(int d, double x) const {
+        switch (d) {
+            case 1: return wave_from_lower1(x);
+            case 2: return wave_from_lower1(wave_from_lower1(x));
+            case 3: return bperm64(lo3, x);
+            default: return bperm64(lo4, x);
+        }
+    }
+    __device__ __forceinline__ double upper(int d, double x) const {
+        switch (d) {
+            case 1: return wave_from_upper1(x);
+            case 2: return wave_from_upper1(wave_from_upper1(x));
+            case 3: return bperm64(up3, x);
+            default: return bperm64(up4, x);
+        }
+    }
+};
+
+// same, with only distance 4 through the LDS crossbar (4 ds_bpermute_b32, 12 DPP moves per stage)
+template <>
+struct Halo<64, HALO_HYBRID1> : Halo<64, HALO_HYBRID> {
+    __device__ __forceinline__ double lower(int d, double x) const {
+        if (d == 3) return wave_from_lower1(wave_from_lower1(wave_from_lower1(x)));
+        return Halo<64, HALO_HYBRID>::lower(d, x);
+    }
+    __device__ __forceinline__ double upper(int d, double x) const {
+        if (d == 3) return wave_from_upper1(wave_from_upper1(wave_from_upper1(x)));
+        return Halo<64, HALO_HYBRID>::upper(d, x);
+    }
 };
 
 // ------------------------------------------------------------------------------------------
@@ -219,6 +265,53 @@ __device__ __forceinline__ void rhs_tile_fast(const double* w, const double* q, 
     }
 }
 
+// FAST-mode rhs of the hybrid one-point-per-lane layout: far neighbours requested first, every term that only needs
+// distances <= 2 computed while they travel.  Same operations in the same per-accumulator order as rhs_tile_fast, so
+// the result is bit-identical to the other fast-mode layouts.
+template <int FAR>   // FAR = 2: distances 3 and 4 by ds_bpermute; FAR = 1: distance 4 only
+__device__ __forceinline__ double rhs_hybrid_fast(const Halo<64, HALO_HYBRID>& h, double u, double phi, const StepArgs& a,
+                                                  double& q0) {
+    double l3, r3;
+    if constexpr (FAR == 2) {
+        l3 = bperm64(h.lo3, u);
+        r3 = bperm64(h.up3, u);
+    }
+    const double l4 = bperm64(h.lo4, u), r4 = bperm64(h.up4, u);
+    __builtin_amdgcn_sched_barrier(0);          // the LDS requests go out FIRST (the scheduler would sink them to their use)
+    const double l1 = wave_from_lower1(u), r1 = wave_from_upper1(u);
+    const double l2 = wave_from_lower1(l1), r2 = wave_from_upper1(r1);
+    if constexpr (FAR == 1) {
+        l3 = wave_from_lower1(l2);
+        r3 = wave_from_upper1(r2);
+    }
+    q0 = u * u;
+    const double ql1 = l1 * l1, qr1 = r1 * r1, ql2 = l2 * l2, qr2 = r2 * r2;
+    double lin = __builtin_fma(a.c_lin[0], u, phi);
+    lin = __builtin_fma(a.c_lin[1], l1 + r1, lin);
+    lin = __builtin_fma(a.c_lin[2], l2 + r2, lin);
+    double bw = (25.0 / 12) * q0;
+    double fw = __builtin_fma(4.0, qr1, -bw);   // fw holds MINUS the forward sum
+    bw = __builtin_fma(-4.0, ql1, bw);
+    fw = __builtin_fma(-3.0, qr2, fw);
+    bw = __builtin_fma(3.0, ql2, bw);
+    if constexpr (FAR == 1) {
+        lin = __builtin_fma(a.c_lin[3], l3 + r3, lin);
+        fw = __builtin_fma(4.0 / 3, r3 * r3, fw);
+        bw = __builtin_fma(-4.0 / 3, l3 * l3, bw);
+    }
+    __builtin_amdgcn_sched_barrier(0);          // keep the far-neighbour terms (and their lgkmcnt wait) behind the near ones
+    if constexpr (FAR == 2) {
+        lin = __builtin_fma(a.c_lin[3], l3 + r3, lin);
+        fw = __builtin_fma(4.0 / 3, r3 * r3, fw);
+        bw = __builtin_fma(-4.0 / 3, l3 * l3, bw);
+    }
+    lin = __builtin_fma(a.c_lin[4], l4 + r4, lin);
+    fw = __builtin_fma(-0.25, r4 * r4, fw);
+    bw = __builtin_fma(0.25, l4 * l4, bw);
+    const double sel = (u < 0.0) ? fw : bw;     // u == 0 selects the backward stencil
+    return __builtin_fma(a.mh_inv_dx, sel, lin);
+}
+
 template <int P>
 __host__ __device__ constexpr int tile_of() { return P % 4 == 0 ? 4 : (P % 3 == 0 ? 3 : (P % 2 == 0 ? 2 : 1)); }
 
@@ -326,12 +419,18 @@ __global__ void __launch_bounds__(256) ks_rk4_fused(const StepArgs a) {
     for (long s = 0; s < a.n_substeps; ++s) {
         double acc[P], us[P], usn[P], w[P + 8], q[P + 8], kk[P];
         // ---- stage 1 (k1 at u) + reward term of this sub-step ----
-        build_window<P, G, HALO, EXACT>(halo, u, w);
+        if constexpr ((HALO == HALO_HYBRID || HALO == HALO_HYBRID1) && !EXACT) {
+            double q0;
+            kk[0] = rhs_hybrid_fast<(HALO == HALO_HYBRID ? 2 : 1)>(halo, u[0], phi[0], a, q0);
+            racc += q0;
+        } else {
+            build_window<P, G, HALO, EXACT>(halo, u, w);
 #pragma unroll
-        for (int i = 0; i < P + 8; ++i) q[i] = w[i] * w[i];
+            for (int i = 0; i < P + 8; ++i) q[i] = w[i] * w[i];
 #pragma unroll
-        for (int j = 0; j < P; ++j) racc += q[4 + j];
-        eval_rhs<P, EXACT>(w, q, phi, a, kk);
+            for (int j = 0; j < P; ++j) racc += q[4 + j];
+            eval_rhs<P, EXACT>(w, q, phi, a, kk);
+        }
 #pragma unroll
         for (int j = 0; j < P; ++j) {
             const double k = kk[j];
@@ -346,10 +445,15 @@ __global__ void __launch_bounds__(256) ks_rk4_fused(const StepArgs a) {
         // ---- stage 2 ----
 #pragma unroll
         for (int j = 0; j < P; ++j) us[j] = usn[j];
-        build_window<P, G, HALO, EXACT>(halo, us, w);
+        if constexpr ((HALO == HALO_HYBRID || HALO == HALO_HYBRID1) && !EXACT) {
+            double q0;
+            kk[0] = rhs_hybrid_fast<(HALO == HALO_HYBRID ? 2 : 1)>(halo, us[0], phi[0], a, q0);
+        } else {
+            build_window<P, G, HALO, EXACT>(halo, us, w);
 #pragma unroll
-        for (int i = 0; i < P + 8; ++i) q[i] = w[i] * w[i];
-        eval_rhs<P, EXACT>(w, q, phi, a, kk);
+            for (int i = 0; i < P + 8; ++i) q[i] = w[i] * w[i];
+            eval_rhs<P, EXACT>(w, q, phi, a, kk);
+        }
 #pragma unroll
         for (int j = 0; j < P; ++j) {
             const double k = kk[j];
@@ -364,10 +468,15 @@ __global__ void __launch_bounds__(256) ks_rk4_fused(const StepArgs a) {
         // ---- stage 3 ----
 #pragma unroll
         for (int j = 0; j < P; ++j) us[j] = usn[j];
-        build_window<P, G, HALO, EXACT>(halo, us, w);
+        if constexpr ((HALO == HALO_HYBRID || HALO == HALO_HYBRID1) && !EXACT) {
+            double q0;
+            kk[0] = rhs_hybrid_fast<(HALO == HALO_HYBRID ? 2 : 1)>(halo, us[0], phi[0], a, q0);
+        } else {
+            build_window<P, G, HALO, EXACT>(halo, us, w);
 #pragma unroll
-        for (int i = 0; i < P + 8; ++i) q[i] = w[i] * w[i];
-        eval_rhs<P, EXACT>(w, q, phi, a, kk);
+            for (int i = 0; i < P + 8; ++i) q[i] = w[i] * w[i];
+            eval_rhs<P, EXACT>(w, q, phi, a, kk);
+        }
 #pragma unroll
         for (int j = 0; j < P; ++j) {
             const double k = kk[j];
@@ -382,10 +491,15 @@ __global__ void __launch_bounds__(256) ks_rk4_fused(const StepArgs a) {
         // ---- stage 4 + update ----
 #pragma unroll
         for (int j = 0; j < P; ++j) us[j] = usn[j];
-        build_window<P, G, HALO, EXACT>(halo, us, w);
+        if constexpr ((HALO == HALO_HYBRID || HALO == HALO_HYBRID1) && !EXACT) {
+            double q0;
+            kk[0] = rhs_hybrid_fast<(HALO == HALO_HYBRID ? 2 : 1)>(halo, us[0], phi[0], a, q0);
+        } else {
+            build_window<P, G, HALO, EXACT>(halo, us, w);
 #pragma unroll
-        for (int i = 0; i < P + 8; ++i) q[i] = w[i] * w[i];
-        eval_rhs<P, EXACT>(w, q, phi, a, kk);
+            for (int i = 0; i < P + 8; ++i) q[i] = w[i] * w[i];
+            eval_rhs<P, EXACT>(w, q, phi, a, kk);
+        }
 #pragma unroll
         for (int j = 0; j < P; ++j) {
             const double k = kk[j];
@@ -596,6 +710,8 @@ __global__ void ks_selftest_kernel(unsigned* out) {
     if (check_halo<64, HALO_DPP_WAVE>()) mask |= 1u << KS_VARIANT_WAVE64_DPP;
     if (check_halo<64, HALO_BPERM>()) mask |= 1u << KS_VARIANT_WAVE64_BPERM;
     if (check_halo<32, HALO_BPERM>()) mask |= 1u << KS_VARIANT_HALF32_BPERM;
+    if (check_halo<64, HALO_HYBRID>()) mask |= 1u << KS_VARIANT_WAVE64_HYBRID;
+    if (check_halo<64, HALO_HYBRID1>()) mask |= 1u << KS_VARIANT_WAVE64_HYBRID1;
     if (mask) atomicOr(out, mask);
 }
 
@@ -635,6 +751,8 @@ bool layout_supported(int variant, int N) {
         case KS_VARIANT_HALF32_BPERM: return N % 32 == 0 && p_supported(N / 32);
         case KS_VARIANT_WAVE64_DPP:
         case KS_VARIANT_WAVE64_BPERM: return N % 64 == 0 && p_supported(N / 64);
+        case KS_VARIANT_WAVE64_HYBRID:
+        case KS_VARIANT_WAVE64_HYBRID1: return N == 64;
         case KS_VARIANT_LDS: return N >= 9 && N <= 2048;
         default: return false;
     }
@@ -648,6 +766,8 @@ hipError_t launch_step(const Layout& lay, int mode, const StepArgs& a, hipStream
         case KS_VARIANT_HALF32_BPERM: KS_P_CASES(32, HALO_BPERM)
         case KS_VARIANT_WAVE64_DPP: KS_P_CASES(64, HALO_DPP_WAVE)
         case KS_VARIANT_WAVE64_BPERM: KS_P_CASES(64, HALO_BPERM)
+        case KS_VARIANT_WAVE64_HYBRID: return lay.P == 1 ? launch_fused<1, 64, HALO_HYBRID>(lay, mode, a, st) : hipErrorInvalidValue;
+        case KS_VARIANT_WAVE64_HYBRID1: return lay.P == 1 ? launch_fused<1, 64, HALO_HYBRID1>(lay, mode, a, st) : hipErrorInvalidValue;
         case KS_VARIANT_LDS:
             if (mode == KS_MODE_EXACT)
                 hipLaunchKernelGGL((ks_rk4_lds<true>), dim3(lay.grid), dim3(lay.block), lay.lds_bytes, st, a);

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "..", "lib", "libkspde.so")
 
 MODE = {"fast": 0, "exact": 1}
 VARIANT = {"auto": 0, "row16_dpp": 1, "row16_bperm": 2, "wave64_dpp": 3, "wave64_bperm": 4,
-           "half32_bperm": 5, "lds": 6}
+           "half32_bperm": 5, "lds": 6, "wave64_hybrid": 7, "wave64_hybrid1": 8}
 VARIANT_NAME = {v: k for k, v in VARIANT.items()}
 
 # every symbol include/kspde.h declares: (name, restype, argtypes)

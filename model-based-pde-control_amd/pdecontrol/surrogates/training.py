@@ -31,6 +31,15 @@ from pdecontrol.surrogates.surrogate import AutoRegPDESurrogate, LatentAutoRegPD
 from pdegym.common.transforms import BatchTransform, Identity, SampleTransform
 
 
+class _GraphOwnedAdam(torch.optim.Adam):
+    """What ``configure_optimizers`` hands to Lightning when the module is ``graphed``: it carries the parameter groups
+    (learning rate, read by schedulers and copied into the captured step's device scalar) but its ``step`` applies
+    nothing -- the Adam update already happened inside the replayed graph."""
+
+    def step(self, closure=None):
+        return None if closure is None else closure()
+
+
 class PDETrainingModule(pl.LightningModule):
     def __init__(self, surrogate: PDESurrogate, loss: Callable, tstep: float, delta: float, env=None,
                  stransf: SampleTransform = None, undscaling: BatchTransform = None, tau: int = 5, tbtt: int = 10,
@@ -175,6 +184,8 @@ class PDETrainingModule(pl.LightningModule):
         except Exception:   # no trainer attached (direct call): the module's own lr
             lr = None
         out = self.fused_step(batch, lr=lr)
+        if lr is not None:
+            opt.step()      # bookkeeping only (_GraphOwnedAdam): keeps scheduler / Lightning step counters consistent
         # the five "Train ..." metrics of the step that was just replayed (static tensors of that captured step)
         for name, value in self.__dict__["_last_graphed_step"].logged.items():
             self.log(name, value, on_step=False, on_epoch=True)
@@ -263,7 +274,10 @@ class PDETrainingModule(pl.LightningModule):
     def configure_optimizers(self):
         params = list(self.surrogate.parameters())
         # same update rule as the reference's Adam; on a GPU as one multi-tensor kernel instead of ~6 per parameter
-        extra = {"fused": True} if params and params[0].is_cuda else {}
-        optimizer = torch.optim.Adam(params, lr=self.lr, **extra)
+        if self.graphed and params and params[0].is_cuda:
+            optimizer = _GraphOwnedAdam(params, lr=self.lr)
+        else:
+            extra = {"fused": True} if params and params[0].is_cuda else {}
+            optimizer = torch.optim.Adam(params, lr=self.lr, **extra)
         scheduler = torch.optim.lr_scheduler.StepLR(optimizer, step_size=self.step_size, gamma=self.lr_gamma)
         return [optimizer], [{"scheduler": scheduler, "interval": "epoch"}]

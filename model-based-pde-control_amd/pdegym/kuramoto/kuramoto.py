@@ -83,6 +83,18 @@ class KuramotoSivashinskyEnv(gym.Env):
     def _l2control(self, obs, *args, **kwargs):
         return (-1.0) * (1 / self.N) * torch.norm(obs) ** 2
 
+    def batched_reward_func(self, obs, phi=None):
+        """``reward_func`` for a whole batch ``[B, ..., N]`` at once (numpy or torch, host or device): the l2control
+        value of every row, in the input's dtype -- what the reference evaluates sample by sample in a Python loop
+        (pdecontrol/mbrl/world/world.py:170).  Only the l2control objective has a batched form."""
+        if not self.objective:
+            raise NotImplementedError("batched reward exists for the l2control objective only")
+        if isinstance(obs, np.ndarray):
+            flat = obs.reshape(obs.shape[0], -1)
+            return ((-1.0) * (1 / self.N) * np.linalg.norm(flat, axis=1) ** 2).astype(obs.dtype)
+        flat = obs.reshape(obs.shape[0], -1)
+        return (-1.0) * (1 / self.N) * torch.linalg.vector_norm(flat, dim=1) ** 2
+
     def _dissipation(self, obs, phi, *args, **kwargs):
         as_np = lambda v: np.squeeze(v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v))
         u, p = as_np(obs).astype(np.float64), as_np(phi)

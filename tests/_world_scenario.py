@@ -4,9 +4,10 @@ import numpy as np
 import torch
 
 
-def run(M, device="cpu"):
+def run(M, device="cpu", world_kwargs=None):
     """M: namespace with Env, T (transforms), Replay, ds, Sample, factory_cls, TrainingModule, Ensemble,
-    WorldVecEnv."""
+    WorldVecEnv.  world_kwargs: extra keywords for this repo's WorldVecEnv -- a callable value is called with the
+    scenario's env (e.g. ``{"batched_reward_func": lambda env: env.batched_reward_func}``)."""
     rec = {}
     env = M.Env()
     T = M.T
@@ -47,7 +48,9 @@ def run(M, device="cpu"):
 
     world = M.WorldVecEnv(surrogate=ensemble, observation_space=env.observation_space, action_space=env.action_space,
                           max_episode_steps=env.max_episode_steps, stransf=replay_to_world.Inverse,
-                          reward_func=env.reward_func, num_envs=4, horizon=3, tstep=tstep)
+                          reward_func=env.reward_func, num_envs=4, horizon=3, tstep=tstep,
+                          **{k: (v(env) if callable(v) else v) for k, v in (world_kwargs or {}).items()})
+    rec_world = world
     rec["single_action_shape"] = np.asarray(world.single_action_space.shape)
     rec["single_obs_shape"] = np.asarray(world.single_observation_space.shape)
     rec["action_low"] = np.asarray(world.single_action_space.low)
@@ -69,4 +72,5 @@ def run(M, device="cpu"):
         rec[f"s{k}_has_final"] = np.asarray("final_observation" in infos)
         if "final_observation" in infos:
             rec[f"s{k}_final"] = np.asarray(infos["final_observation"])
+    run.last_world = rec_world
     return rec

@@ -12,10 +12,12 @@ from conftest import KS_CONFIGS
 
 pytestmark = pytest.mark.gpu
 
-FUSED = ["row16_dpp", "row16_bperm", "wave64_dpp", "wave64_bperm", "half32_bperm", "lds"]
+FUSED = ["row16_dpp", "row16_bperm", "wave64_dpp", "wave64_bperm", "half32_bperm", "lds", "wave64_hybrid", "wave64_hybrid1"]
 
 
 def _supported(variant, N):
+    if variant.startswith("wave64_hybrid"):
+        return N == 64
     P = {"row16": 16, "wave64": 64, "half32": 32}.get(variant.split("_")[0])
     if P is None:
         return 9 <= N <= 2048

@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.join(ROOT, "model-based-pde-control_amd"))
 import kspde  # noqa: E402
 
 CASES = [(1024, 64, 22.0), (4096, 256, 88.0), (4096, 64, 22.0), (16384, 64, 22.0), (32768, 256, 88.0)]
-VARIANTS = ["row16_dpp", "row16_bperm", "wave64_dpp", "wave64_bperm", "half32_bperm", "lds"]
+VARIANTS = ["row16_dpp", "row16_bperm", "wave64_dpp", "wave64_bperm", "wave64_hybrid", "wave64_hybrid1", "half32_bperm", "lds"]
 
 
 def run(E, N, L, variant, block, mode, nsub=250, reps=5):
