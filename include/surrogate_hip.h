@@ -169,6 +169,12 @@ int sur_flush_chunk_grads(void* stream, const sur_chunk_params* p, const sur_ada
 int sur_flush_all_grads(void* stream, const sur_encoder_params* e0, const sur_adam* a0, const sur_encoder_params* e1,
                         const sur_adam* a1, const sur_chunk_params* c2, const sur_adam* a2, int overwrite_mask);
 
+/* torch.optim.Adam step of up to three packs FROM their gradient tensors g[] in one launch (the optimizer of the eager
+ * fused path: reference pdecontrol/surrogates/training.py:273-278 driven by pl.Trainer.fit, mbrl.py:593).  A NULL
+ * descriptor skips its pack.  Moments / step counter / device learning rate as in sur_adam above. */
+int sur_adam_apply(void* stream, const sur_encoder_params* e0, const sur_adam* a0, const sur_encoder_params* e1,
+                   const sur_adam* a1, const sur_chunk_params* c2, const sur_adam* a2);
+
 /* Delta-mode TBPTT loss in one launch (reference: pdecontrol/surrogates/training.py:100-121):
  *   deltas[b,t]  = ((states[b,t+1] - states[b,t]) / delta - mean) / stdv          t < T-1   (undscaling forward)
  *   loss         = mean over (b, t < T-1, i) of (d_all[t,b,i] - deltas[b,t,i])^2  (MSE, reduction "none" + mean)

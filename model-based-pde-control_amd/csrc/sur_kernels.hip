@@ -1818,6 +1818,49 @@ flush_all_kernel(const sur_encoder_params e0, const sur_adam a0, int n0, const s
     else flush_grads_body<SUR_ST_NPARAM, sur_chunk_params>(c2, n2, a2, overwrite_mask & 4, blk - b0 - b1, b2);
 }
 
+// torch.optim.Adam (no weight decay / amsgrad) of a whole parameter pack from its gradient tensors: the optimizer of the
+// EAGER fused path (pdecontrol.surrogates.hipops.PackAdam) -- one launch instead of torch's per-step Python bookkeeping.
+// Same arithmetic as the Adam branch of flush_grads_body.
+template <int NP, typename Params>
+__device__ __forceinline__ void adam_apply_body(const Params& p, int psize, const sur_adam& adam, int blk, int nblk) {
+    const int t = blk * TPB + threadIdx.x;
+    const int step = *adam.step + 1;   // read before this block takes its ticket
+    const float lr = *adam.lr;
+    if (t < psize) {
+        int off = 0;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            if (t >= off && t < off + p.size[i]) {
+                const float g = p.g[i][t - off];
+                const float m = adam.beta1 * adam.m[t] + (1.0f - adam.beta1) * g;
+                const float v = adam.beta2 * adam.v[t] + (1.0f - adam.beta2) * g * g;
+                adam.m[t] = m;
+                adam.v[t] = v;
+                const float bc1 = 1.0f - powf(adam.beta1, (float)step), bc2 = 1.0f - powf(adam.beta2, (float)step);
+                const float denom = sqrtf(v) / sqrtf(bc2) + adam.eps;
+                float* w = const_cast<float*>(p.w[i]);
+                w[t - off] -= (lr / bc1) * (m / denom);
+            }
+            off += p.size[i];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(adam.ticket, 1u) == (unsigned)(nblk - 1)) {
+        *adam.step = step;
+        *adam.ticket = 0u;
+    }
+}
+
+__global__ void __launch_bounds__(TPB)
+adam_all_kernel(const sur_encoder_params e0, const sur_adam a0, int n0, const sur_encoder_params e1, const sur_adam a1, int n1,
+                const sur_chunk_params c2, const sur_adam a2, int n2) {
+    const int b0 = (n0 + TPB - 1) / TPB, b1 = (n1 + TPB - 1) / TPB, b2 = (n2 + TPB - 1) / TPB;
+    const int blk = blockIdx.x;
+    if (blk < b0) adam_apply_body<SUR_ENC_NPARAM, sur_encoder_params>(e0, n0, a0, blk, b0);
+    else if (blk < b0 + b1) adam_apply_body<SUR_ENC_NPARAM, sur_encoder_params>(e1, n1, a1, blk - b0, b1);
+    else adam_apply_body<SUR_ST_NPARAM, sur_chunk_params>(c2, n2, a2, blk - b0 - b1, b2);
+}
+
 template <typename F>
 int launch_checked(F&& f, const char* what) {
     f();
@@ -2177,6 +2220,46 @@ int sur_flush_all_grads(void* stream, const sur_encoder_params* e0, const sur_ad
         hipLaunchKernelGGL(flush_all_kernel, dim3(grid), dim3(TPB), 0, (hipStream_t)stream, *e0, ad[0], n0, *e1, ad[1], n1, *c2, ad[2],
                            n2, overwrite_mask);
     }, "flush_all");
+}
+
+int sur_adam_apply(void* stream, const sur_encoder_params* e0, const sur_adam* a0, const sur_encoder_params* e1,
+                   const sur_adam* a1, const sur_chunk_params* c2, const sur_adam* a2) {
+    // a pack without a descriptor is skipped (its size counts as 0)
+    const sur_adam* in[3] = {a0, a1, a2};
+    sur_adam ad[3] = {};
+    for (int j = 0; j < 3; ++j)
+        if (in[j]) {
+            if (!in[j]->m || !in[j]->v || !in[j]->step || !in[j]->ticket || !in[j]->lr)
+                return fail(-1, "sur_adam_apply: incomplete Adam descriptor %d", j);
+            ad[j] = *in[j];
+        }
+    if ((a0 && !e0) || (a1 && !e1) || (a2 && !c2)) return fail(-1, "sur_adam_apply: descriptor without its parameter pack");
+    sur_encoder_params pe0{}, pe1{};
+    sur_chunk_params pc2{};
+    int n0 = 0, n1 = 0, n2 = 0;
+    if (a0) {
+        pe0 = *e0;
+        n0 = psize_of<SUR_ENC_NPARAM>(e0->size);
+        for (int i = 0; i < SUR_ENC_NPARAM; ++i)
+            if (!e0->g[i] || !e0->w[i]) return fail(-1, "sur_adam_apply: encoder 0 tensor %d is NULL", i);
+    }
+    if (a1) {
+        pe1 = *e1;
+        n1 = psize_of<SUR_ENC_NPARAM>(e1->size);
+        for (int i = 0; i < SUR_ENC_NPARAM; ++i)
+            if (!e1->g[i] || !e1->w[i]) return fail(-1, "sur_adam_apply: encoder 1 tensor %d is NULL", i);
+    }
+    if (a2) {
+        pc2 = *c2;
+        n2 = psize_of<SUR_ST_NPARAM>(c2->size);
+        for (int i = 0; i < SUR_ST_NPARAM; ++i)
+            if (!c2->g[i] || !c2->w[i]) return fail(-1, "sur_adam_apply: chunk tensor %d is NULL", i);
+    }
+    const int grid = (n0 + TPB - 1) / TPB + (n1 + TPB - 1) / TPB + (n2 + TPB - 1) / TPB;
+    if (grid == 0) return 0;
+    return launch_checked([&] {
+        hipLaunchKernelGGL(adam_all_kernel, dim3(grid), dim3(TPB), 0, (hipStream_t)stream, pe0, ad[0], n0, pe1, ad[1], n1, pc2, ad[2], n2);
+    }, "adam_all");
 }
 
 int sur_tbptt_delta_loss(void* stream, const float* states, long states_bstride, long states_tstride, const float* d_all, int b,

@@ -271,13 +271,22 @@ class PDETrainingModule(pl.LightningModule):
         data.update({"states": states.numpy(), "outputs": outputs.numpy(), "actions": actions.numpy()})
         return data
 
+    def _fused_eager(self):
+        from pdecontrol.surrogates import hipops, ops
+        return ops.fused_enabled() and hipops.fused_supported(self.surrogate)
+
     def configure_optimizers(self):
         params = list(self.surrogate.parameters())
         # same update rule as the reference's Adam; on a GPU as one multi-tensor kernel instead of ~6 per parameter
-        if self.graphed and params and params[0].is_cuda:
+        on_gpu = bool(params) and params[0].is_cuda
+        if self.graphed and on_gpu:
             optimizer = _GraphOwnedAdam(params, lr=self.lr)
+        elif on_gpu and self._fused_eager():
+            # the whole Adam update as ONE launch over the fused packs' flat state (same rule as torch.optim.Adam)
+            from pdecontrol.surrogates import hipops
+            optimizer = hipops.PackAdam(self.surrogate, lr=self.lr)
         else:
-            extra = {"fused": True} if params and params[0].is_cuda else {}
+            extra = {"fused": True} if on_gpu else {}
             optimizer = torch.optim.Adam(params, lr=self.lr, **extra)
         scheduler = torch.optim.lr_scheduler.StepLR(optimizer, step_size=self.step_size, gamma=self.lr_gamma)
         return [optimizer], [{"scheduler": scheduler, "interval": "epoch"}]

@@ -47,12 +47,15 @@ class _History:
         self.values = np.zeros((num_envs, num_steps) + tuple(item_shape), dtype=dtype)
         self.mask = np.zeros((num_envs, num_steps), dtype=np.bool_)
 
-    def push(self, items):
-        # write into slot 0, then rotate left: slot 0 (the oldest) becomes the newest, at the end
-        self.values[:, 0] = items
-        self.values = np.roll(self.values, -1, axis=1)
-        self.mask[:, 0] = True
-        self.mask = np.roll(self.mask, -1, axis=1)
+
+def _push(history, items):
+    """The reference writes the new item into slot 0 and rotates left with ``np.roll`` (a fresh copy of the whole
+    history per step).  Same resulting array, shifted in place: older items move one slot towards 0, the new item
+    lands in the last slot.  (The controller's stacks use ``num_steps = 1``, where this is a plain overwrite; the
+    reference's consumers copy what they read, pdecontrol/mbrl/worker.py:50,70,75.)"""
+    if history.shape[1] > 1:
+        history[:, :-1] = history[:, 1:]
+    history[:, -1] = items
 
 
 class StoreNObsVecWrapper(_Wrapper):
@@ -73,10 +76,8 @@ class StoreNObsVecWrapper(_Wrapper):
             done = infos["_final_observation"]
             self.finals[done] = np.expand_dims(_final_rows(infos), axis=1)
             self.mask[done] = False
-        self.obs[:, 0] = obs
-        self.obs = np.roll(self.obs, -1, axis=1)
-        self.mask[:, 0] = True
-        self.mask = np.roll(self.mask, -1, axis=1)
+        _push(self.obs, obs)
+        _push(self.mask, True)
         return obs, rewards, terminated, truncated, infos
 
     def reset(self, **kwargs) -> Any:
@@ -99,10 +100,8 @@ class StoreNActionsVecWrapper(_Wrapper):
         self.actions, self.mask = hist.values, hist.mask
 
     def step_async(self, actions: Sequence[Any]) -> None:
-        self.actions[:, 0] = actions
-        self.mask[:, 0] = True
-        self.actions = np.roll(self.actions, -1, axis=1)
-        self.mask = np.roll(self.mask, -1, axis=1)
+        _push(self.actions, actions)
+        _push(self.mask, True)
         return super().step_async(actions)
 
     def step_wait(self, **kwargs: Any):

@@ -72,3 +72,31 @@ def test_wrappers_on_batched_ks_env_shapes():
     assert astore.mask[:, -1].all()
     # env-side actions are the agent's actions scaled by 2 (ScaleTransform(bounds=+-2).Inverse)
     np.testing.assert_allclose(vec.stepper.u.shape, (4, 64))
+
+
+@pytest.mark.gpu
+def test_six_wrapper_stack_on_batched_hip_env_against_reference_stack():
+    """The controller's six-wrapper stack on the HBM-resident KSBatchedVecEnv (exact arithmetic mode, seeded resets with
+    the full GPU burn-in) against arrays recorded from the REFERENCE's wrappers stacked on three instances of the
+    REFERENCE's KuramotoSivashinskyEnv (oracle/gen_golden.py::wrapper_ks_fixtures).  Observations, stored histories
+    and the running min / max of the observation scaling are bit-exact (the state is bit-identical and everything
+    after it is fp32 elementwise arithmetic); rewards to 1e-12 (the reference sums its per-sub-step terms in another
+    order)."""
+    from pdegym.kuramoto import make_vec
+    g = np.load(os.path.join(os.path.dirname(GOLDEN), "wrappers_ks_golden.npz"))
+    vec = make_vec(3, step_mode="exact", reset_mode="exact")
+    top, ostore, astore, oscaling = build_stack(vec)
+    obs, info = top.reset(return_info=True, seed=int(g["seed"]))
+    np.testing.assert_array_equal(obs, g["reset_obs"])
+    np.testing.assert_array_equal(info["step"], g["reset_step"])
+    np.testing.assert_array_equal(np.asarray(top.observation_space.shape), g["obs_space_shape"])
+    for k, a in enumerate(g["actions"]):
+        top.step_async(a)
+        obs, rew, term, trunc, infos = top.step_wait()
+        for name, got in (("obs", obs), ("trunc", trunc), ("step", infos["step"]),
+                          ("ostore_obs", ostore.obs), ("ostore_mask", ostore.mask), ("ostore_finals", ostore.finals),
+                          ("astore_actions", astore.actions), ("astore_mask", astore.mask),
+                          ("vmin", np.asarray(oscaling.vmin)), ("vmax", np.asarray(oscaling.vmax))):
+            np.testing.assert_array_equal(np.asarray(got), g[f"s{k}_{name}"], err_msg=f"step {k}: {name}")
+        np.testing.assert_allclose(rew, g[f"s{k}_rew"], rtol=1e-12, err_msg=f"step {k}: reward")
+        assert "final_observation" not in infos
