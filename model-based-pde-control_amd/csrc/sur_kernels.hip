@@ -872,9 +872,12 @@ __host__ __device__ inline int enc_ws_floats(const sur_encoder_params& p) {
     return p.c[1] * h1 + p.c[2] * h2;
 }
 
+// LDS of the block backward: only what rb_backward reads is resident -- the input, four of the seven saved intermediates
+// (a1pre, a1, a2pre: contiguous in the record; s), and scratch that reuses dead buffers (g2 over dout, g3 over s).
+// 2 nin + 7 a floats instead of 2 nin + 13 a: at N = 256 a third workgroup fits a CU.
 __host__ __device__ inline int enc_block_act_floats(const EncBlockGeom& g) {
     const int a = g.cout * g.hout, nin = g.cin * g.hin;
-    return nin + 7 * a + 4 * a + a + nin;   // in, intermediates, g1 g2 g3 xh, dout, din
+    return nin + 4 * a + 2 * a + a + nin;   // in, {a1pre a1 a2pre s}, {g1 xh}, dout (= g2), din
 }
 
 struct EncBlockJob {
@@ -894,11 +897,12 @@ __device__ __forceinline__ void enc_block_bwd_body(const EncBlockJob& j, int blk
     rb.cin = gm.cin; rb.cout = gm.cout; rb.hin = gm.hin; rb.hout = gm.hout; rb.stride = gm.stride;
     float* cur = lds;
     rb.in = cur; cur += nin;
-    rb.skip = cur; rb.a1pre = cur + a; rb.a1 = cur + 2 * a; rb.a2pre = cur + 3 * a; rb.a2 = cur + 4 * a; rb.s = cur + 5 * a;
-    rb.out = cur + 6 * a; cur += 7 * a;
-    float *g1 = cur, *g2 = cur + a, *g3 = cur + 2 * a, *xh = cur + 3 * a;
-    cur += 4 * a;
+    rb.a1pre = cur; rb.a1 = cur + a; rb.a2pre = cur + 2 * a; rb.s = cur + 3 * a; cur += 4 * a;   // skip, a2, out: not read
+    float *g1 = cur, *xh = cur + a;
+    cur += 2 * a;
     float* dout = cur; cur += a;
+    float* g2 = dout;     // dout is consumed by the first LayerNorm backward, before g2 is written
+    float* g3 = rb.s;     // likewise s
     float* din = cur; cur += nin;
     ParamViews<SUR_RB_NPARAM> v;
     stage_weights<SUR_RB_NPARAM>(p.w + SUR_RB_NPARAM * blk, p.size + SUR_RB_NPARAM * blk, cur, v);
@@ -915,7 +919,8 @@ __device__ __forceinline__ void enc_block_bwd_body(const EncBlockJob& j, int blk
         // this block's input, its seven intermediates, the gradient wrt its output: all loads of a round in flight
         if (gm.in_saved_off < 0) lds_load(rb.in, j.x + (size_t)m * nin, nin);
         else lds_load_v4(rb.in, rec + gm.in_saved_off, nin >> 2);
-        lds_load_v4(rb.skip, rec + gm.saved_off, (7 * a) >> 2);
+        lds_load_v4(rb.a1pre, rec + gm.saved_off + a, (3 * a) >> 2);      // record: skip | a1pre a1 a2pre | a2 | s | out
+        lds_load_v4(rb.s, rec + gm.saved_off + 5 * a, a >> 2);
         const float* dsrc = blk == 2 ? j.dz + (size_t)m * a : j.ws + (size_t)m * nws + (blk == 1 ? ws_out_off : 0);
         lds_load_v4(dout, dsrc, a >> 2);
         rb_backward(rb, v.w, v.g, dout, din, g1, g2, g3, xh);
@@ -1248,26 +1253,30 @@ __device__ void decoder_forward(const sur_chunk_params& p, const StepLayout& L, 
     STAMP(9);
 }
 
-// decoder backward on LDS-resident activations: L.gA holds d loss / d d on entry, L.dh the gradient wrt hnew on exit
+// decoder backward on LDS-resident activations: L.gA holds d loss / d d on entry, L.dh the gradient wrt hnew on exit.
+// LDS is what limits the (step, sample)-parallel kernel to one workgroup per CU at N = 256, so nothing is allocated
+// that a dead buffer can serve: the LayerNorm backward's normalised-activation scratch lives in the post-LayerNorm
+// activation that was consumed just before (a2 for the last norm, a1 -- dead after the 7-tap weight gradient -- for the
+// other two), and L.dh may alias L.gB (free once the first norm's backward has read it).
 __device__ void decoder_backward(const sur_chunk_params& p, const StepLayout& L, const float* const* w, float* const* g) {
     const int n = L.n;
     conv_bwd_weight<5>(L.gA, 1, L.a2, 1, n, 1, 2, g[SUR_ST_CV3_W], g[SUR_ST_CV3_B], all_waves(), false);
     STAMP(12);
     conv_bwd_data<5>(L.gA, 1, n, w[SUR_ST_CV3_W], 1, 1, 2, L.gB, false);
     STAMP(13);
-    act_ln_bwd(L.gB, L.p2, 1, n, w[SUR_ST_LN2_W], true, L.gA, L.xh, g[SUR_ST_LN2_W], g[SUR_ST_LN2_B]);
+    act_ln_bwd(L.gB, L.p2, 1, n, w[SUR_ST_LN2_W], true, L.gA, L.a2, g[SUR_ST_LN2_W], g[SUR_ST_LN2_B]);
     STAMP(14);
     conv_bwd_weight<7>(L.gA, 1, L.a1, p.c_mid, n, 1, 3, g[SUR_ST_CV2_W], g[SUR_ST_CV2_B], all_waves(), false);
     STAMP(15);
     conv_bwd_data<7>(L.gA, 1, n, w[SUR_ST_CV2_W], p.c_mid, 1, 3, L.gB, false);
     STAMP(16);
-    act_ln_bwd(L.gB, L.p1, p.c_mid, n, w[SUR_ST_LN1_W], true, L.gA, L.xh, g[SUR_ST_LN1_W], g[SUR_ST_LN1_B]);
+    act_ln_bwd(L.gB, L.p1, p.c_mid, n, w[SUR_ST_LN1_W], true, L.gA, L.a1, g[SUR_ST_LN1_W], g[SUR_ST_LN1_B]);
     STAMP(17);
     deconv_bwd_weight(L.gA, p.c_mid, L.a0, p.cs, 2 * p.hq, g[SUR_ST_DC1_W], g[SUR_ST_DC1_B], lower_half(), false);
     STAMP(18);
     deconv_bwd_data(L.gA, p.c_mid, 2 * p.hq, w[SUR_ST_DC1_W], p.cs, L.gB, upper_half(), true);
     STAMP(19);
-    act_ln_bwd(L.gB, L.p0, p.cs, 2 * p.hq, w[SUR_ST_LN0_W], true, L.gA, L.xh, g[SUR_ST_LN0_W], g[SUR_ST_LN0_B]);
+    act_ln_bwd(L.gB, L.p0, p.cs, 2 * p.hq, w[SUR_ST_LN0_W], true, L.gA, L.a1, g[SUR_ST_LN0_W], g[SUR_ST_LN0_B]);
     STAMP(26);
     deconv_bwd_weight(L.gA, p.cs, L.hnew, p.cs, p.hq, g[SUR_ST_DC0_W], g[SUR_ST_DC0_B], lower_half(), false);
     STAMP(27);
@@ -1385,9 +1394,8 @@ __host__ __device__ inline int cell_wgrad_act_floats(const sur_chunk_params& p) 
 }
 __host__ __device__ inline int dec_act_floats(const sur_chunk_params& p, bool backward) {
     const int s = p.cs * p.hq, n = 4 * p.hq;
-    int total = s + dec_part_floats(p) + n;             // hnew, p0..a2, d
-    if (backward) total += 3 * step_max_act(p) + s;      // gA, gB, xh, dh
-    return total;
+    if (backward) return s + dec_part_floats(p) + 2 * step_max_act(p);   // hnew, p0..a2, gA, gB (dh aliases gB)
+    return s + dec_part_floats(p) + n;                                    // hnew, p0..a2, d
 }
 
 template <int NP>
@@ -1532,12 +1540,10 @@ dec_bwd_kernel(const sur_chunk_params p, const float* __restrict__ saved, const 
     L.a1 = L.p1 + p.c_mid * n;
     L.p2 = L.a1 + p.c_mid * n;
     L.a2 = L.p2 + n;
-    L.d = L.a2 + n;
-    L.gA = L.d + n;
+    L.gA = L.a2 + n;
     L.gB = L.gA + mx;
-    L.xh = L.gB + mx;
-    L.dh = L.xh + mx;
-    float* wbase = L.dh + s;
+    L.dh = L.gB;              // s <= mx: the first LayerNorm's backward has consumed gB before dh is written
+    float* wbase = L.gB + mx;
     const float* w[SUR_ST_NPARAM];
     stage_range<ST_NDEC>(p, ST_NLSTM, wbase, w);
     int off_dec = 0, psize_dec = 0;
@@ -2054,6 +2060,9 @@ int sur_chunk_saved_floats(const sur_chunk_params* p) {
     if (!p) return 0;
     // the GEMM tiles want whole 16-wide latent rows; the cell backward moves [gates | c] in whole 1 KiB DMA pieces
     if ((p->hq & 15) || ((p->ca * p->hq) & 3) || (5 * p->cs * p->hq) % DMA_PIECE || p->cs * p->hq > CELL_EPT * TPB) return 0;
+    // the decoder backward keeps its LayerNorm scratch in dead activation buffers (decoder_backward): a1 (+ p2, a2 behind it)
+    // must hold a [cs][2 hq] tile, and dh [cs][hq] must fit the gradient ping-pong buffer
+    if (p->cs * 2 * p->hq > p->c_mid * 4 * p->hq + 8 * p->hq || p->cs * p->hq > step_max_act(*p)) return 0;
     return step_saved_floats(*p);
 }
 
