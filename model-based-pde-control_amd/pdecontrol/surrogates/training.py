@@ -56,6 +56,8 @@ class PDETrainingModule(pl.LightningModule):
             self.training_mode = "delta"
         elif isinstance(surrogate, LatentAutoRegPDESurrogate):
             self.training_mode = "decoded"
+        elif getattr(surrogate, "training_mode", None) in ("delta", "decoded"):
+            self.training_mode = surrogate.training_mode      # e.g. the FNO surrogate of the Burgers path (f4)
         else:
             raise ValueError
         assert self.tbtt > self.tau, "Chunk size of TBTT must be larger than warm-up length."

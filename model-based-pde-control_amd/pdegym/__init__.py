@@ -1,8 +1,8 @@
 """pdegym -- PDE control environments (MI355X-native build).
 
 Importing the package registers the environments with gym, like the reference's
-``pdegym/__init__.py`` -- minus its import of ``pdegym.burgers``, a module that does not exist in
-the reference tree (its ``import pdegym`` fails as shipped).
+``pdegym/__init__.py`` -- including ``pdegym.burgers``, which the reference imports but does not ship
+(its ``import pdegym`` fails as shipped): here that module exists (pdegym/burgers).
 
 Batched GPU vector envs: set ``PDEGYM_BATCHED=1`` (or call ``install_batched_vector_make()``) and
 ``gym.vector.make("KuramotoSivashinskyEnv-v0", num_envs=E)`` -- the call the reference's
@@ -12,6 +12,7 @@ subprocess envs, so ``pdecontrol/mbrl/script.py`` needs no edit.
 import os
 
 from pdegym._gym import gym, IS_SHIM
+import pdegym.burgers  # noqa: F401  (registers BurgersEnv-v0; loads no GPU library until an env is built)
 import pdegym.kuramoto  # noqa: F401  (registers the env ids)
 
 

@@ -594,6 +594,34 @@ def wrapper_ks_fixtures():
     return rec
 
 
+def burgers_fixtures():
+    """the reference has no Burgers env; its discretisation lives in BurgersPhyPDELoss
+    (pdecontrol/surrogates/phyloss/phyloss.py:36-86).  Record residual() and phyevolve() of that class on smooth and
+    rough periodic fields at N = 512 (BASELINE configs[4]) and N = 128, fp32, plus ten chained phyevolve steps."""
+    import pdecontrol.surrogates.phyloss.phyloss as phy
+    out = {}
+    for tag, N, L, nu, dt in (("n512", 512, 2 * np.pi, 0.01, 1e-3), ("n128", 128, 2 * np.pi, 0.05, 2e-3)):
+        dx = L / N
+        loss = phy.BurgersPhyPDELoss(dx=dx, dt=dt, nu=nu)
+        x = np.linspace(0, L, N, endpoint=False)
+        rs = np.random.RandomState(11)
+        smooth = np.stack([sum(rs.uniform(-1, 1) * np.sin((k + 1) * x + rs.uniform(0, 6)) for k in range(4)) for _ in range(6)])
+        rough = rs.uniform(-1, 1, (2, N))
+        u = torch.from_numpy(np.concatenate([smooth, rough]).astype(np.float32)).reshape(2, 4, 1, N)   # [B, T, C, H]
+        with torch.no_grad():
+            res = loss.residual(u)
+            evo = loss.phyevolve(u)
+            chain = u.clone()
+            for _ in range(10):
+                chain = loss.phyevolve(chain)
+        out[f"{tag}_u"] = u.numpy().reshape(8, N).copy()
+        out[f"{tag}_residual"] = res.numpy().reshape(8, N).copy()
+        out[f"{tag}_evolve"] = evo.numpy().reshape(8, N).copy()
+        out[f"{tag}_evolve10"] = chain.numpy().reshape(8, N).copy()
+        out[f"{tag}_params"] = np.asarray([dx, dt, nu, L], dtype=np.float64)
+    return out
+
+
 def dataset_fixtures():
     """replay -> sub-sequence datasets -> loaders, and the curriculum schedulers."""
     here = os.path.dirname(os.path.abspath(__file__))
@@ -650,7 +678,7 @@ def world_fixtures(ks):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-reset", action="store_true", help="skip the two ~50 s burn-in resets")
-    ap.add_argument("--only", choices=["ks", "surrogate", "surrogate256", "wrappers", "wrappers_ks", "dataset", "world"], default=None)
+    ap.add_argument("--only", choices=["ks", "surrogate", "surrogate256", "wrappers", "wrappers_ks", "dataset", "world", "burgers"], default=None)
     args = ap.parse_args()
     if not os.path.isdir(REF):
         sys.exit("reference not present: fixtures can only be generated in the build container")
@@ -680,6 +708,10 @@ def main():
         fx = dataset_fixtures()
         np.savez_compressed(os.path.join(OUT, "dataset_golden.npz"), **fx)
         print("dataset_golden.npz:", len(fx), "arrays")
+    if args.only in (None, "burgers"):
+        fx = burgers_fixtures()
+        np.savez_compressed(os.path.join(OUT, "burgers_golden.npz"), **fx)
+        print("burgers_golden.npz:", len(fx), "arrays")
     if args.only in (None, "wrappers_ks"):
         fx = wrapper_ks_fixtures()
         np.savez_compressed(os.path.join(OUT, "wrappers_ks_golden.npz"), **fx)
