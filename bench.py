@@ -250,6 +250,63 @@ class KSRun:
         return elapsed, float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
 
+def burgers_fno_leg(dev, steps=30, warmup=5):
+    """BASELINE configs[4] (second PDE path; the reference ships neither a Burgers env nor an FNO, so nothing here has a
+    reference-side pin beyond the discretisation, tests/test_burgers.py): the fp32 Burgers stepper at 512 grid points and
+    one eager TBPTT training step of the FNO-style surrogate on the fused spectral-convolution kernel."""
+    from pdegym.burgers import make_vec
+    E, N = 8192, 512
+    env = make_vec(E, config=dict(N=N), device=dev.index or 0)
+    env.reset(seed=0)
+    acts = torch.from_numpy(np.random.RandomState(5).uniform(-1, 1, (steps + warmup, E, 4)).astype(np.float32)).to(dev)
+    for i in range(warmup):
+        env.step_torch(acts[i])
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    for i in range(steps):
+        ev[i][0].record()
+        env.step_torch(acts[warmup + i])
+        ev[i][1].record()
+    torch.cuda.synchronize(dev)
+    assert int(env._status.sum()) == 0
+    ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    alg = 12.0 * N * E * env.cfg_steps           # fp32: read u, write u, read phi per env-sub-step
+    out = {"workload": f"Burgers nu={env.nu} N={N} dt={env.dt} cfg_steps={env.cfg_steps}, {E} batched envs (BASELINE.json configs[4], "
+                       f"one GPU's share), fp32",
+           "value": E * env.cfg_steps / (ms * 1e-3), "unit": "sub-steps/s", "avg_launch_ms": ms,
+           "roofline": {"bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg,
+                        "note": "algorithmic 12*N B per env-sub-step (fp32 u in, u out, phi); state in VGPRs for all 50 "
+                                "sub-steps, so like the KS stepper the kernel is VALU-issue bound, not HBM bound"}}
+    # FNO surrogate: eager training_step + backward + Adam, B = 64, T = 20, N = 512 (width 32, 16 modes, 4 layers)
+    from pdecontrol.architectures import BurgersFNO
+    from pdecontrol.surrogates.training import PDETrainingModule
+    torch.manual_seed(0)
+    f = BurgersFNO()
+    sur = f.surrogate(delta=0.05, dscaling=None, tau=5, **f.model())
+    mod = PDETrainingModule(surrogate=sur, loss=torch.nn.MSELoss(reduction="none"), tstep=0.05, delta=0.05, tau=5, tbtt=10).to(dev)
+    g = torch.Generator().manual_seed(1)
+    batch = ((torch.rand(64, 20, 1, N, generator=g) * 2 - 1).to(dev), (torch.rand(64, 20, 1, N, generator=g) * 2 - 1).to(dev))
+    opt = mod.configure_optimizers()[0][0]
+
+    def one():
+        o = mod.training_step(batch, 0)
+        opt.zero_grad(set_to_none=True)
+        o["loss"].backward()
+        opt.step()
+    for _ in range(3):
+        one()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(10):
+        one()
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / 10
+    out["fno_tbptt"] = {"value": 64 / dt, "unit": "seqs/s", "ms_per_step": dt * 1e3,
+                        "config": {"factory": "BurgersFNO", "width": 32, "modes": 16, "layers": 4, "B": 64, "T": 20, "N": N},
+                        "path": "eager; spectral convolutions on the fused truncated-DFT HIP kernel, pointwise GEMMs on rocBLAS"}
+    return out
+
+
 def measured_hbm_copy_gbs(dev, mib=1024, reps=10):
     """Device-to-device copy rate of this box (read + write bytes per second), SURVEY 8(d): the measured companion of
     the nominal 8 TB/s the roofline fraction is quoted against."""
@@ -278,6 +335,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tbptt", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--no-burgers", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -383,6 +441,11 @@ def main():
                 out["tbptt"] = bench_tbptt.run(device=dev, cpu=cpu_tbptt)
             except Exception as exc:  # never lose the KS line to the secondary measurement
                 out["tbptt"] = {"error": f"{type(exc).__name__}: {exc}"}
+        if not args.no_burgers and not args.no_secondary:
+            try:
+                out["burgers_fno"] = burgers_fno_leg(dev)
+            except Exception as exc:
+                out["burgers_fno"] = {"error": f"{type(exc).__name__}: {exc}"}
     if dist is not None and not args.no_tbptt:
         # data-parallel surrogate step at N = 256: B = 64 sequences per rank, one flat-bucket all-reduce per step
         try:

@@ -106,12 +106,22 @@ __global__ void __launch_bounds__(TPB, 2) spec_conv_kernel(const Args a) {
         for (int e = threadIdx.x; e < c_out * M; e += blockDim.x) {
             const int o = e / M, m = e - o * M;
             float yr = 0.0f, yi = 0.0f;
-            for (int i = 0; i < c_in; ++i) {
-                const float xr = S[i * KP + m], xi = S[i * KP + M + m];
-                const size_t wi_ = ((size_t)i * a.cout + o) * M + m;
-                const float wr = a.wr[wi_], wi = a.wi[wi_];
-                yr = fmaf(xr, wr, fmaf(-xi, wi, yr));
-                yi = fmaf(xr, wi, fmaf(xi, wr, yi));
+            const size_t wstep = (size_t)a.cout * M;
+            const float* pr = a.wr + (size_t)o * M + m;
+            const float* pi = a.wi + (size_t)o * M + m;
+            for (int i0 = 0; i0 < c_in; i0 += 16) {       // channels are multiples of 16: 32 weight loads in flight
+                float wr[16], wi[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    wr[u] = pr[(size_t)(i0 + u) * wstep];
+                    wi[u] = pi[(size_t)(i0 + u) * wstep];
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const float xr = S[(i0 + u) * KP + m], xi = S[(i0 + u) * KP + M + m];
+                    yr = fmaf(xr, wr[u], fmaf(-xi, wi[u], yr));
+                    yi = fmaf(xr, wi[u], fmaf(xi, wr[u], yi));
+                }
             }
             const float s = m == 0 ? s0 : s1;
             Z[o * KP + m] = s * yr;
@@ -134,12 +144,21 @@ __global__ void __launch_bounds__(TPB, 2) spec_conv_kernel(const Args a) {
         for (int e = threadIdx.x; e < c_out * M; e += blockDim.x) {   // c_out = Cin of the forward operator
             const int i = e / M, m = e - i * M;
             float gr = 0.0f, gi = 0.0f;
-            for (int o = 0; o < c_in; ++o) {
-                const float yr = S[o * KP + m], yi = S[o * KP + M + m];
-                const size_t wi_ = ((size_t)i * a.cout + o) * M + m;
-                const float wr = a.wr[wi_], wi = a.wi[wi_];
-                gr = fmaf(yr, wr, fmaf(yi, wi, gr));
-                gi = fmaf(yi, wr, fmaf(-yr, wi, gi));
+            const float* pr = a.wr + (size_t)i * a.cout * M + m;
+            const float* pi = a.wi + (size_t)i * a.cout * M + m;
+            for (int o0 = 0; o0 < c_in; o0 += 16) {
+                float wr[16], wi[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    wr[u] = pr[(size_t)(o0 + u) * M];
+                    wi[u] = pi[(size_t)(o0 + u) * M];
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const float yr = S[(o0 + u) * KP + m], yi = S[(o0 + u) * KP + M + m];
+                    gr = fmaf(yr, wr[u], fmaf(yi, wi[u], gr));
+                    gi = fmaf(yi, wr[u], fmaf(-yr, wi[u], gi));
+                }
             }
             Z[i * KP + m] = gr;
             Z[i * KP + M + m] = gi;

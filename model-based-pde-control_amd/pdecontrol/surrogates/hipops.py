@@ -160,6 +160,12 @@ class _Pack:
             assert p.is_cuda and p.is_contiguous() and p.dtype == torch.float32
             self.c.w[i] = p.data_ptr()
 
+    def grads_are_own_views(self):
+        """True when every param.grad still IS the view of the pack-owned flat buffer handed out by the last flush (the
+        kernel's gradient pointers are then current)."""
+        views = self._gviews
+        return views is not None and all(p.grad is v for p, v in zip(self.params, views))
+
     def resolve_grads(self):
         """Gradient addresses, taken when the reduction is about to be launched.  Sets ``self.overwrite``."""
         grads = [p.grad for p in self.params]
@@ -427,14 +433,19 @@ class PackAdam(torch.optim.Optimizer):
                 loss = closure()
         packs = self._packs()
         group = self.param_groups[0]
-        descs = packs.adam_descriptors(group["lr"], group["betas"], group["eps"])
+        key = (id(packs), tuple(group["betas"]), group["eps"])
+        if self.__dict__.get("_desc_key") != key:       # descriptors are built once; only the device lr changes per step
+            self._descs, self._desc_key = packs.adam_descriptors(group["lr"], group["betas"], group["eps"]), key
+        packs.set_lr(group["lr"])
         live = []
-        for pack, desc in zip(packs.packs, descs):
-            if all(p.grad is None for p in pack.params):
+        for pack, desc in zip(packs.packs, self._descs):
+            if pack.grads_are_own_views():               # the usual case: what the flush of this step just handed out
+                live.append(desc)
+            elif all(p.grad is None for p in pack.params):
                 live.append(None)
-                continue
-            pack.resolve_grads()
-            live.append(desc)
+            else:
+                pack.resolve_grads()
+                live.append(desc)
         if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
             world = torch.distributed.get_world_size()
             for pack, desc in zip(packs.packs, live):

@@ -356,3 +356,31 @@ def test_fused_tbptt_other_chunkings(dev, T):
     assert gf.keys() == gt.keys()
     for k in gt:
         _close(gf[k], gt[k], rtol=1e-2, atol_scale=8e-5, msg=k)
+
+
+def test_pack_adam_matches_torch_adam_and_lightning_closure_order(dev):
+    """configure_optimizers() on a GPU hands out PackAdam (one launch over the packs' flat moments).  Five eager steps in
+    pytorch-lightning's order (training_step -> zero_grad(set_to_none) -> backward -> step) against torch.optim.Adam on
+    the same kernels; a StepLR-style learning-rate change in between must reach the device scalar."""
+    from pdecontrol.surrogates import hipops
+    from pdecontrol.surrogates.bench_tbptt import build_module, synthetic_batch
+    batch = synthetic_batch(B=8, device=dev)
+    ref, m = build_module(dev), build_module(dev)
+    opt_ref = torch.optim.Adam(ref.surrogate.parameters(), lr=ref.lr)
+    opt = m.configure_optimizers()[0][0]
+    assert isinstance(opt, hipops.PackAdam)
+    for k in range(5):
+        if k == 3:
+            for o in (opt_ref, opt):
+                o.param_groups[0]["lr"] = 2.5e-4
+        for mod, o in ((ref, opt_ref), (m, opt)):
+            out = mod.training_step(batch, 0)
+            o.zero_grad(set_to_none=True)
+            out["loss"].backward()
+            o.step()
+    torch.cuda.synchronize(dev)
+    assert m.surrogate._fused_packs.adam_step_count() == 5
+    for (name, p), q in zip(m.surrogate.named_parameters(), ref.surrogate.parameters()):
+        np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), rtol=2e-5, atol=2e-7, err_msg=name)
+    sd = opt.state_dict()
+    assert sd["packs"][2]["step"] == 5 and sd["param_groups"][0]["lr"] == 2.5e-4
