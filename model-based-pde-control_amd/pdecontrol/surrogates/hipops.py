@@ -145,14 +145,19 @@ class _Pack:
         self.refresh()
 
     def ensure_rows(self, rows):
-        if self.partial is None or self.partial.shape[0] < rows:
+        """Make rows [0, rows) available.  The allocation grows geometrically (and superseded buffers are retired, not
+        freed); ``c.rows`` -- what the backward launches are checked against and what the flush reduces and re-zeroes --
+        is the largest row count ever REQUESTED, so the reduction never walks allocation slack."""
+        self.need_rows = max(getattr(self, "need_rows", 0), int(rows))
+        if self.partial is None or self.partial.shape[0] < self.need_rows:
             assert not self.dirty, "cannot grow the partial-gradient buffer with unflushed gradients"
+            alloc = self.need_rows
             if self.partial is not None:
                 self._retired.append(self.partial)   # addresses baked into captured graphs stay valid (and zeroed)
-                rows = max(rows, (3 * self.partial.shape[0]) // 2)
-            rows = (rows + 127) // 128 * 128
-            self.partial = torch.zeros((rows, self.psize), device=self.params[0].device, dtype=torch.float32)
-        self.c.partial, self.c.rows = self.partial.data_ptr(), self.partial.shape[0]
+                alloc = max(alloc, (3 * self.partial.shape[0]) // 2)
+            alloc = (alloc + 127) // 128 * 128
+            self.partial = torch.zeros((alloc, self.psize), device=self.params[0].device, dtype=torch.float32)
+        self.c.partial, self.c.rows = self.partial.data_ptr(), self.need_rows
 
     def refresh(self):
         """Weight addresses (forward pass)."""
@@ -343,7 +348,7 @@ class FusedPacks:
 
     def refresh_partials(self):
         for pack in self.packs:
-            pack.c.partial, pack.c.rows = pack.partial.data_ptr(), pack.partial.shape[0]
+            pack.c.partial, pack.c.rows = pack.partial.data_ptr(), pack.need_rows
 
     def flush(self):
         """Reduce every pending partial-gradient row into param.grad (3 tiny launches at most)."""

@@ -160,7 +160,10 @@ def test_shape_switch_keeps_one_adam_state(fused):
         assert len(m._graphed_steps) == 2
         np.testing.assert_allclose(l_mod, l_ref, rtol=3e-5)
         for (name, p), q in zip(m.surrogate.named_parameters(), ref.surrogate.parameters()):
-            np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), rtol=1e-4, atol=1e-6, err_msg=name)
+            # Adam moves a parameter by up to lr per step whatever the gradient's magnitude: a near-zero gradient whose
+            # rounding differs between two runs (the plain path's MIOpen reductions are not bit-reproducible) shows up as
+            # a few 1e-6 after five steps; a restarted optimizer state would show up as ~1e-3
+            np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), rtol=1e-4, atol=2e-5, err_msg=name)
         if fused:
             assert m.surrogate._fused_packs.adam_step_count() == len(seq)
 
