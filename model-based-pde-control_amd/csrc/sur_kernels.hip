@@ -1137,13 +1137,17 @@ __host__ __device__ inline int step_saved_floats(const sur_chunk_params& p) {
     return (step_block_floats(p) + DMA_PIECE - 1) / DMA_PIECE * DMA_PIECE;
 }
 
-// ConvLSTM cell with the gate non-linearities in the GEMM epilogue (4 waves, cs = 16): wave w owns channels
-// 4w .. 4w+3 and its 16 tile rows are (channel, gate) pairs, so after the K loop lane (q, n) holds the four gate
+// ConvLSTM cell with the gate non-linearities in the GEMM epilogue (4 * T waves, cs = 16): wave group w = wave & 3 owns
+// channels 4w .. 4w+3 and its 16 tile rows are (channel, gate) pairs, so after the K loop lane (q, n) holds the four gate
 // pre-activations of channel 4w+q at position n in its four accumulator registers -- i, f, g, o, c' and h' are finished
-// in registers: no second pass over LDS, one barrier per step instead of two.
+// in registers: no second pass over LDS, one barrier per step instead of two.  The hq / 16 column tiles are spread over
+// the T = blockDim / 256 wave sets (the chain runs ONE workgroup per sample on a quarter of the CUs: at hq = 64 sixteen
+// waves finish the recurrent step's GEMM in one tile each instead of four in a row).
+template <int NSETS>
 __device__ void cell_forward_fused(const sur_chunk_params& p, const StepLayout& L, const float* const* w) {
     const int s = p.cs * p.hq, hq = p.hq, ca = p.ca, cs = p.cs;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3, tset = NSETS > 1 ? threadIdx.x >> 8 : 0;
+    constexpr int nsets = NSETS;
     const int r = lane & 15, q = lane >> 4;
     const int gate_stride = (int)(w[SUR_ST_WXF] - w[SUR_ST_WXI]);
     const int gate_r = r & 3, ch_r = 4 * wave + (r >> 2);                 // identity of this lane's A row
@@ -1152,7 +1156,7 @@ __device__ void cell_forward_fused(const sur_chunk_params& p, const StepLayout& 
     const int ch = 4 * wave + q;                                           // channel of this lane's accumulators
     const float bi = w[SUR_ST_BXI][ch], bf = (w[SUR_ST_BXI] + gate_stride)[ch], bc = (w[SUR_ST_BXI] + 2 * gate_stride)[ch],
                 bo = (w[SUR_ST_BXI] + 3 * gate_stride)[ch];
-    for (int n0 = 0; n0 < hq; n0 += 16) {
+    for (int n0 = 16 * tset; n0 < hq; n0 += 16 * nsets) {
         const int n = n0 + r;
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1187,12 +1191,21 @@ __device__ void cell_forward_fused(const sur_chunk_params& p, const StepLayout& 
     __syncthreads();
 }
 
-// ConvLSTM cell on LDS-resident x, h, c: fills gates (activated), cnew, hnew
+// ConvLSTM cell on LDS-resident x, h, c: fills gates (activated), cnew, hnew.  BLOCK = blockDim.x when it is known at
+// compile time (the chain kernels), 0 otherwise.
+template <int BLOCK = 0>
 __device__ void cell_forward(const sur_chunk_params& p, const StepLayout& L, const float* const* w) {
     const int s = p.cs * p.hq;
-    if (blockDim.x == 256 && p.cs == 16 && p.ca <= 4) {
-        cell_forward_fused(p, L, w);
-        return;
+    if constexpr (BLOCK >= 256 && (BLOCK & 255) == 0) {
+        if (p.cs == 16 && p.ca <= 4) {
+            cell_forward_fused<BLOCK / 256>(p, L, w);
+            return;
+        }
+    } else {
+        if (blockDim.x == 256 && p.cs == 16 && p.ca <= 4) {
+            cell_forward_fused<1>(p, L, w);
+            return;
+        }
     }
     STAMP(0);
     // all four gates' pre-activations in ONE gather-GEMM: rows = (gate, channel), K = 3*(ca + cs).
@@ -1383,6 +1396,11 @@ constexpr int ST_NLSTM = SUR_ST_DC0_W;              // the LSTM parameters come 
 constexpr int ST_NDEC = SUR_ST_NPARAM - ST_NLSTM;
 
 __host__ __device__ inline int cell_part_floats(const sur_chunk_params& p) { return 6 * p.cs * p.hq; }
+// threads of a cell-chain workgroup: one 256-thread wave set per 16-wide column tile of the latent, at most four
+inline int cell_chain_threads(const sur_chunk_params& p) {
+    const int sets = p.hq / 16;
+    return TPB * (sets < 1 ? 1 : (sets > 4 ? 4 : sets));
+}
 __host__ __device__ inline int dec_part_floats(const sur_chunk_params& p) { return step_block_floats(p) - cell_part_floats(p); }
 __host__ __device__ inline int cell_fwd_act_floats(const sur_chunk_params& p) { return p.ca * p.hq + 8 * p.cs * p.hq; }
 __host__ __device__ inline int cell_bwd_act_floats(const sur_chunk_params& p) {
@@ -1406,7 +1424,9 @@ __device__ __forceinline__ void stage_range(const sur_chunk_params& p, int first
     for (int i = 0; i < NP; ++i) w[first + i] = v.w[i];
 }
 
-__global__ void __launch_bounds__(TPB)
+// (the chain kernels are instantiated per workgroup size: the 256-thread build keeps its register budget)
+template <int MAXT>
+__global__ void __launch_bounds__(MAXT)
 cell_fwd_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, const float* __restrict__ lstates_t,
                 const float* __restrict__ h0, const float* __restrict__ c0, int hc_bstride, int K, int S, int B,
                 float* __restrict__ h_all, float* __restrict__ c_all, float* __restrict__ saved) {
@@ -1429,14 +1449,15 @@ cell_fwd_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, cons
     // the next step's latent action is fetched while this step computes
     float xn[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) xn[u] = threadIdx.x + u * TPB < nx ? xlat_t[(size_t)b * nx + threadIdx.x + u * TPB] : 0.0f;
+    for (int u = 0; u < 4; ++u)
+        xn[u] = threadIdx.x + u * MAXT < nx ? xlat_t[(size_t)b * nx + threadIdx.x + u * MAXT] : 0.0f;
     __syncthreads();
     for (int k = 0; k < K; ++k) {
         const size_t kb = (size_t)k * B + b;
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (threadIdx.x + u * TPB < nx) L.x[threadIdx.x + u * TPB] = xn[u];
-        for (int i = threadIdx.x + 4 * TPB; i < nx; i += blockDim.x) L.x[i] = xlat_t[kb * nx + i];
+            if (threadIdx.x + u * MAXT < nx) L.x[threadIdx.x + u * MAXT] = xn[u];
+        for (int i = threadIdx.x + 4 * MAXT; i < nx; i += MAXT) L.x[i] = xlat_t[kb * nx + i];
         for (int i = threadIdx.x; i < s; i += blockDim.x) {
             L.h[i] = (k < S) ? lstates_t[kb * s + i] : L.hnew[i];  // teacher forcing replaces H
             L.c[i] = L.cnew[i];
@@ -1445,9 +1466,9 @@ cell_fwd_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, cons
         if (k + 1 < K) {
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                if (threadIdx.x + u * TPB < nx) xn[u] = xlat_t[(kb + B) * nx + threadIdx.x + u * TPB];
+                if (threadIdx.x + u * MAXT < nx) xn[u] = xlat_t[(kb + B) * nx + threadIdx.x + u * MAXT];
         }
-        cell_forward(p, L, w);
+        cell_forward<MAXT>(p, L, w);
         for (int i = threadIdx.x; i < s; i += blockDim.x) {
             h_all[kb * s + i] = L.hnew[i];
             c_all[kb * s + i] = L.cnew[i];
@@ -1587,7 +1608,8 @@ struct ChunkSpans {
     sur_chunk_span sp[SUR_MAX_SPANS];
     int n;
 };
-__global__ void __launch_bounds__(TPB)
+template <int MAXT>
+__global__ void __launch_bounds__(MAXT)
 cell_bwd_kernel(const sur_chunk_params p, const ChunkSpans spans, const float* __restrict__ c_all,
                 const float* __restrict__ saved, const float* __restrict__ dh_dec, const float* __restrict__ dh_all,
                 const float* __restrict__ dc_all, int B, float* __restrict__ dg_all, float* __restrict__ dh0,
@@ -1619,7 +1641,7 @@ cell_bwd_kernel(const sur_chunk_params p, const ChunkSpans spans, const float* _
     auto prefetch = [&](int kk) {   // c_{kk-1} and the decoder's dh of step kk
 #pragma unroll
         for (int e = 0; e < CELL_EPT; ++e) {
-            const int i = threadIdx.x + e * TPB;
+            const int i = threadIdx.x + e * MAXT;
             if (i < s) {
                 cp[e] = (kk > K0) ? c_all[((size_t)(kk - 1) * B + b) * s + i] : c0[(size_t)b * hc_bstride + i];
                 dhd[e] = dh_dec[((size_t)kk * B + b) * s + i];
@@ -1641,7 +1663,7 @@ cell_bwd_kernel(const sur_chunk_params p, const ChunkSpans spans, const float* _
         const float* g_ = k >= K0 ? blk[k & 1] : nullptr;
 #pragma unroll
         for (int e = 0; e < CELL_EPT; ++e) {
-            const int i = threadIdx.x + e * TPB;
+            const int i = threadIdx.x + e * MAXT;
             if (i >= s) continue;
             float dh_in = 0.0f;
             if (have_prev) {
@@ -2083,13 +2105,20 @@ int sur_chunk_forward(void* stream, const sur_chunk_params* p, const float* xlat
     for (int i = ST_NLSTM; i < SUR_ST_NPARAM; ++i) psize_dec += p->size[i];
     const size_t lds_cell = sizeof(float) * (cell_fwd_act_floats(*p) + psize_lstm);
     const size_t lds_dec = sizeof(float) * (dec_act_floats(*p, false) + psize_dec);
-    if (int rc = set_lds(cell_fwd_kernel, lds_cell, "cell forward")) return rc;
     if (int rc = set_lds(dec_fwd_kernel, lds_dec, "decoder forward")) return rc;
     const int m = k * b, n = 4 * p->hq;
-    if (int rc = launch_checked([&] {
-            hipLaunchKernelGGL(cell_fwd_kernel, dim3(b), dim3(TPB), lds_cell, (hipStream_t)stream, *p, xlat_t, lstates_t, h0, c0,
+    const int chain_threads = cell_chain_threads(*p);
+    auto launch_cell_fwd = [&](auto kernel) -> int {
+        if (int rc = set_lds(kernel, lds_cell, "cell forward")) return rc;
+        return launch_checked([&] {
+            hipLaunchKernelGGL(kernel, dim3(b), dim3(chain_threads), lds_cell, (hipStream_t)stream, *p, xlat_t, lstates_t, h0, c0,
                                hc_bstride, k, s, b, h_all, c_all, saved);
-        }, "cell_fwd")) return rc;
+        }, "cell_fwd");
+    };
+    if (int rc = chain_threads == TPB ? launch_cell_fwd(cell_fwd_kernel<TPB>)
+                                      : (chain_threads == 2 * TPB ? launch_cell_fwd(cell_fwd_kernel<2 * TPB>)
+                                                                  : launch_cell_fwd(cell_fwd_kernel<4 * TPB>)))
+        return rc;
     if (int rc = launch_checked([&] {
             hipLaunchKernelGGL(dec_fwd_kernel, dim3(m < 1024 ? m : 1024), dim3(TPB), lds_dec, (hipStream_t)stream, *p, h_all, m,
                                d_all, saved);
@@ -2140,17 +2169,24 @@ static int chunks_backward_impl(void* stream, const sur_chunk_params* p, const C
     const int wg_gl = wg_base + sizeof(float) * psize_lstm <= LDS_LIMIT ? 1 : 0;
     const size_t lds_wg = wg_base + (wg_gl ? sizeof(float) * psize_lstm : 0);
     if (int rc = set_lds(dec_bwd_kernel, lds_dec, "decoder backward")) return rc;
-    if (int rc = set_lds(cell_bwd_kernel, lds_cell, "cell backward")) return rc;
     if (int rc = set_lds(cell_wgrad_kernel, lds_wg, "cell weight gradients")) return rc;
     const int grid = m < row_count ? m : row_count;
     if (int rc = launch_checked([&] {
             hipLaunchKernelGGL(dec_bwd_kernel, dim3(grid), dim3(TPB), lds_dec, (hipStream_t)stream, *p, saved, ga, m, dh_dec, dec_gl,
                                row_base);
         }, "dec_bwd")) return rc;
-    if (int rc = launch_checked([&] {
-            hipLaunchKernelGGL(cell_bwd_kernel, dim3(spans.n * b), dim3(TPB), lds_cell, (hipStream_t)stream, *p, spans, c_all, saved,
+    const int chain_threads = cell_chain_threads(*p);
+    auto launch_cell_bwd = [&](auto kernel) -> int {
+        if (int rc = set_lds(kernel, lds_cell, "cell backward")) return rc;
+        return launch_checked([&] {
+            hipLaunchKernelGGL(kernel, dim3(spans.n * b), dim3(chain_threads), lds_cell, (hipStream_t)stream, *p, spans, c_all, saved,
                                dh_dec, dh_all, dc_all, b, dg_all, dh0, dc0);
-        }, "cell_bwd")) return rc;
+        }, "cell_bwd");
+    };
+    if (int rc = chain_threads == TPB ? launch_cell_bwd(cell_bwd_kernel<TPB>)
+                                      : (chain_threads == 2 * TPB ? launch_cell_bwd(cell_bwd_kernel<2 * TPB>)
+                                                                  : launch_cell_bwd(cell_bwd_kernel<4 * TPB>)))
+        return rc;
     return launch_checked([&] {
         hipLaunchKernelGGL(cell_wgrad_kernel, dim3(grid), dim3(TPB), lds_wg, (hipStream_t)stream, *p, spans, xlat_t, h_all, dg_all,
                            k_total, b, dxlat_t, wg_gl, row_base);
