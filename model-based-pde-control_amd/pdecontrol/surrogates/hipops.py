@@ -796,9 +796,11 @@ class _Fork:
     capture (the side work becomes a parallel branch of the graph).  With ``inner_forks(False)`` the block
     simply runs on the current stream."""
 
-    def __init__(self, stream):
+    def __init__(self, stream, worthwhile=True):
         self.main = torch.cuda.current_stream(stream.device)
-        self.forked = _INNER_FORKS
+        # ``worthwhile`` = False: the caller knows the step is host-bound when run eagerly (small grids: the GPU waits
+        # for Python, a fork only adds events and stream switches); under capture the fork always pays (a graph branch)
+        self.forked = _INNER_FORKS and (worthwhile or torch.cuda.is_current_stream_capturing())
         self.stream = stream if self.forked else self.main
 
     def __enter__(self):
@@ -857,7 +859,7 @@ class _TBPTTFn(torch.autograd.Function):
                                           ssaved[0].data_ptr()), action_job(*bounds[0])])
         # the other action latents on the side stream: with `split`, forked AFTER the launches above (which fill the
         # device anyway) so that they run beside chunk 0's cell chain, which occupies only B of the 256 CUs
-        fork = _Fork(side)
+        fork = _Fork(side, worthwhile=n >= 128)
         lat_ready = {}
         with fork:
             for c, (k0, k1) in enumerate(bounds):
@@ -873,9 +875,10 @@ class _TBPTTFn(torch.autograd.Function):
                     ev = torch.cuda.Event()
                     ev.record(fork.stream)
                     lat_ready[c] = ev
-            for t in (asaved, lactions_t, actions_t):
-                if t is not None:
-                    t.record_stream(torch.cuda.current_stream(dev))
+            if fork.forked:
+                for t in (asaved, lactions_t, actions_t):
+                    if t is not None:
+                        t.record_stream(torch.cuda.current_stream(dev))
         if not split:
             _check(lib.sur_encoder_forward(_stream(), ctypes.byref(owner.state_enc.c), _p(states_t0), tau * b, _p(lstates[0]),
                                            _p(ssaved[0])))

@@ -107,3 +107,31 @@ def test_vec_env_device_resident_step(api):
     np.testing.assert_array_equal(obs.cpu().numpy(), o_ref)
     np.testing.assert_allclose(rew.cpu().numpy(), r_ref, rtol=1e-14)
     assert not trunc.any() and int(status.sum()) == 0
+
+
+def test_gym_make_and_vector_make_reach_the_hip_stepper(api, ks_golden, monkeypatch):
+    """The calls the reference's controller makes (pdecontrol/mbrl/mbrl.py:78-86): ``gym.make(ENV_ID, new_step_api=True)`` ->
+    this repo's ``make`` -> env on the HIP stepper inside TimeLimit; ``gym.vector.make(ENV_ID, num_envs=E)`` -> the batched
+    env once ``install_batched_vector_make()`` (or PDEGYM_BATCHED=1) routed it.  gym itself is absent from the image: the
+    registry / TimeLimit are the in-repo shim's (their gym 0.25.2 semantics are unpinned); the arithmetic is pinned --
+    a seeded reset through ``gym.make`` equals the reference's reset bit for bit."""
+    import pdegym
+    from pdegym._gym import gym
+    from pdegym.kuramoto import ENV_ID, KSBatchedVecEnv
+    env = gym.make(ENV_ID, new_step_api=True, config={"step_mode": "exact"})
+    obs = env.reset(seed=int(ks_golden["n64_reset_seed"]))
+    np.testing.assert_array_equal(np.asarray(obs)[0], ks_golden["n64_reset_u"])
+    inner = env.unwrapped
+    inner.u = ks_golden["n64_traj_u0"][0]
+    obs, rew, term, trunc, info = env.step(ks_golden["n64_actions"][0])
+    np.testing.assert_array_equal(obs[0], ks_golden["n64_traj_u250"][0])
+    assert not term and not trunc and info["step"] == 1
+    # the time limit: max_episode_steps = ceil(Tmax / (dt * cfg_steps))
+    short = gym.make(ENV_ID, new_step_api=True, config={"Tmax": 0.5})
+    short.reset(seed=3)
+    flags = [short.step(np.zeros((1, 4), np.float32))[3] for _ in range(2)]
+    assert flags == [False, True]
+    pdegym.install_batched_vector_make(device=0)
+    vec = gym.vector.make(ENV_ID, num_envs=5, config={"Tmax": 0.5}, burn_in=False)
+    assert isinstance(vec, KSBatchedVecEnv) and vec.num_envs == 5 and vec.reset(seed=1).shape == (5, 1, 64)
+    vec.close()
