@@ -304,6 +304,19 @@ def burgers_fno_leg(dev, steps=30, warmup=5):
     out["fno_tbptt"] = {"value": 64 / dt, "unit": "seqs/s", "ms_per_step": dt * 1e3,
                         "config": {"factory": "BurgersFNO", "width": 32, "modes": 16, "layers": 4, "B": 64, "T": 20, "N": N},
                         "path": "eager; spectral convolutions on the fused truncated-DFT HIP kernel, pointwise GEMMs on rocBLAS"}
+    try:   # the same step captured as one hipGraph (PDETrainingModule.fused_step is architecture-agnostic)
+        mod.fused_step(batch)
+        for _ in range(2):
+            mod.fused_step(batch)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(10):
+            mod.fused_step(batch)
+        torch.cuda.synchronize(dev)
+        dg = (time.perf_counter() - t0) / 10
+        out["fno_tbptt"]["hip_graph"] = {"value": 64 / dg, "ms_per_step": dg * 1e3}
+    except Exception as exc:
+        out["fno_tbptt"]["hip_graph"] = {"error": f"{type(exc).__name__}: {exc}"}
     return out
 
 

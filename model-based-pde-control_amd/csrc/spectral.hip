@@ -8,6 +8,9 @@
 //        forward :  Y[o][m] = s_m * sum_i S[i][m] * W[i][o][m]           s_0 = 1/N, s_m = 2/N (irfft's weights)
 //        backward:  G = s (.) S is saved;  GX[i][m] = sum_o G[o][m] * conj(W[i][o][m])
 //   C  out[c][n] = sum_k Z[c][k] * Bi[k][n]:  Bi[m][n] = cos(th), Bi[M + m][n] = -sin(th)   ([C x 2M] @ [2M x N] GEMM)
+// When it fits (it does at BASELINE configs[4]: C = 32, N = 512, 16 modes -> 142 KB of the 160 KB), the twiddle matrix
+// Bf[n][k] (= Bi[k][n]) is materialised in LDS once per workgroup, so the GEMM loops gather two operands and do no index
+// arithmetic; larger geometries gather from the N-entry cosine table instead (DENSE = false).
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
@@ -49,15 +52,16 @@ __device__ __forceinline__ float twiddle(const float* tab, int k, int pos, int M
     return is_sin ? -tab[(idx - quarter) & nmask] : tab[idx];
 }
 
-__global__ void __launch_bounds__(TPB, 2) spec_conv_kernel(const Args a) {
+template <bool DENSE>
+__global__ void __launch_bounds__(TPB) spec_conv_kernel(const Args a) {
     extern __shared__ __align__(16) float lds[];
     const int N = a.n, M = a.m, K2 = 2 * M;
     const int c_in = a.backward ? a.cout : a.cin;     // channels of this launch's input / output tensors
     const int c_out = a.backward ? a.cin : a.cout;
     const int NP = N + 4, KP = K2 + 4;
     float* xs = lds;                       // [c_in][NP]
-    float* tab = xs + c_in * NP;           // [N]
-    float* S = tab + N;                    // [c_in][KP]
+    float* tab = xs + c_in * NP;           // DENSE: Bf [N][KP]; else cos table [N]
+    float* S = tab + (DENSE ? N * KP : N); // [c_in][KP]
     float* Z = S + c_in * KP;              // [c_out][KP]
     const int b = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
@@ -71,8 +75,32 @@ __global__ void __launch_bounds__(TPB, 2) spec_conv_kernel(const Args a) {
         const int e = i << 2, c = e / N, p = e - c * N;
         *reinterpret_cast<float4*>(xs + c * NP + p) = v;
     }
-    for (int k = threadIdx.x; k < N; k += blockDim.x) tab[k] = cospif(2.0f * (float)k / (float)N);
+    if constexpr (DENSE) {
+        // N cosines per workgroup (two per thread), then the [N][2M] matrix by table look-up: evaluating 2 M N
+        // transcendental functions here cost 16 of the kernel's 40 us
+        float* ctab = S;                                  // S / Z are not live yet: N <= (c_in + c_out) * KP is checked on the host
+        for (int k = threadIdx.x; k < N; k += blockDim.x) ctab[k] = cospif(2.0f * (float)k / (float)N);
+        __syncthreads();
+        if ((K2 & (K2 - 1)) == 0) {           // the usual 16 modes: shifts instead of a runtime division per entry
+            const int sh = __ffs(K2) - 1;
+            for (int i = threadIdx.x; i < N * K2; i += blockDim.x) {
+                const int pos = i >> sh, k = i & (K2 - 1);
+                tab[pos * KP + k] = twiddle(ctab, k, pos, M, nmask, quarter);
+            }
+        } else {
+            for (int i = threadIdx.x; i < N * K2; i += blockDim.x) {
+                const int pos = i / K2, k = i - pos * K2;
+                tab[pos * KP + k] = twiddle(ctab, k, pos, M, nmask, quarter);
+            }
+        }
+    } else {
+        for (int k = threadIdx.x; k < N; k += blockDim.x) tab[k] = cospif(2.0f * (float)k / (float)N);
+    }
     __syncthreads();
+    auto tw = [&](int k, int pos) -> float {   // twiddle of spectrum column / row k at grid position pos
+        if constexpr (DENSE) return tab[pos * KP + k];
+        else return twiddle(tab, k, pos, M, nmask, quarter);
+    };
 
     // ---- A: truncated DFT, S [c_in][2M] ------------------------------------------------------------------------
     {
@@ -81,14 +109,18 @@ __global__ void __launch_bounds__(TPB, 2) spec_conv_kernel(const Args a) {
             const int rt = t / ctiles, ct = t - rt * ctiles;
             const int col = 16 * ct + r;
             const float* arow = xs + (16 * rt + r) * NP;
-            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-            for (int k0 = 0; k0 < N; k0 += 8) {      // two independent accumulators
-                const int p0 = k0 + q, p1 = k0 + 4 + q;
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[p0], twiddle(tab, col, p0, M, nmask, quarter), acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[p1], twiddle(tab, col, p1, M, nmask, quarter), acc1, 0, 0, 0);
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f}, acc3 = {0.f, 0.f, 0.f, 0.f};
+            for (int k0 = 0; k0 < N; k0 += 16) {     // four independent accumulators, eight operand loads in flight (N % 32 == 0)
+                const int p0 = k0 + q, p1 = k0 + 4 + q, p2 = k0 + 8 + q, p3 = k0 + 12 + q;
+                const float a0 = arow[p0], a1 = arow[p1], a2 = arow[p2], a3 = arow[p3];
+                const float b0 = tw(col, p0), b1 = tw(col, p1), b2 = tw(col, p2), b3 = tw(col, p3);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc1, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b2, acc2, 0, 0, 0);
+                acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b3, acc3, 0, 0, 0);
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) S[(16 * rt + 4 * q + j) * KP + col] = acc0[j] + acc1[j];
+            for (int j = 0; j < 4; ++j) S[(16 * rt + 4 * q + j) * KP + col] = (acc0[j] + acc1[j]) + (acc2[j] + acc3[j]);
         }
     }
     __syncthreads();
@@ -103,29 +135,67 @@ __global__ void __launch_bounds__(TPB, 2) spec_conv_kernel(const Args a) {
                 dst[i] = S[c * KP + k];
             }
         }
-        for (int e = threadIdx.x; e < c_out * M; e += blockDim.x) {
-            const int o = e / M, m = e - o * M;
-            float yr = 0.0f, yi = 0.0f;
-            const size_t wstep = (size_t)a.cout * M;
-            const float* pr = a.wr + (size_t)o * M + m;
-            const float* pi = a.wi + (size_t)o * M + m;
-            for (int i0 = 0; i0 < c_in; i0 += 16) {       // channels are multiples of 16: 32 weight loads in flight
-                float wr[16], wi[16];
+        // The weights ([Cin][Cout][M] x 2, 128 KB at width 32 / 16 modes) stream through the sample's LDS buffer -- dead
+        // after phase A -- in slabs of `ch` input channels: coalesced 16-byte loads, every thread busy, instead of
+        // 4-byte gathers whose latency four waves cannot cover (that gather WAS the kernel: 42 of its 44 us).
+        const int slab = a.cout * M;                       // floats of one input channel's [Cout][M] weight plane
+        int ch = 8;
+        while (ch > 1 && (2 * ch * slab > c_in * NP || (c_in % ch))) ch >>= 1;
+        const bool staged = 2 * ch * slab <= c_in * NP && !(slab & 3);
+        float* wbuf_r = xs;
+        float* wbuf_i = xs + ch * slab;
+        constexpr int EPT = 4;                             // outputs per thread: Cout * M <= 4 * 256 (checked on the host)
+        float yr[EPT], yi[EPT];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    wr[u] = pr[(size_t)(i0 + u) * wstep];
-                    wi[u] = pi[(size_t)(i0 + u) * wstep];
+        for (int u = 0; u < EPT; ++u) yr[u] = yi[u] = 0.0f;
+        if (staged) {
+            for (int i0 = 0; i0 < c_in; i0 += ch) {
+                __syncthreads();
+                const float4* gr = reinterpret_cast<const float4*>(a.wr + (size_t)i0 * slab);
+                const float4* gi = reinterpret_cast<const float4*>(a.wi + (size_t)i0 * slab);
+                for (int j = threadIdx.x; j < (ch * slab) >> 2; j += blockDim.x) {
+                    reinterpret_cast<float4*>(wbuf_r)[j] = gr[j];
+                    reinterpret_cast<float4*>(wbuf_i)[j] = gi[j];
                 }
+                __syncthreads();
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const float xr = S[(i0 + u) * KP + m], xi = S[(i0 + u) * KP + M + m];
-                    yr = fmaf(xr, wr[u], fmaf(-xi, wi[u], yr));
-                    yi = fmaf(xr, wi[u], fmaf(xi, wr[u], yi));
+                for (int u = 0; u < EPT; ++u) {
+                    const int e = threadIdx.x + u * TPB;
+                    if (e < c_out * M) {
+                        const int m = e % M;
+                        for (int c = 0; c < ch; ++c) {
+                            const float xr = S[(i0 + c) * KP + m], xi = S[(i0 + c) * KP + M + m];
+                            const float wr = wbuf_r[c * slab + e], wi = wbuf_i[c * slab + e];
+                            yr[u] = fmaf(xr, wr, fmaf(-xi, wi, yr[u]));
+                            yi[u] = fmaf(xr, wi, fmaf(xi, wr, yi[u]));
+                        }
+                    }
                 }
             }
-            const float s = m == 0 ? s0 : s1;
-            Z[o * KP + m] = s * yr;
-            Z[o * KP + M + m] = s * yi;
+        } else {
+#pragma unroll
+            for (int u = 0; u < EPT; ++u) {
+                const int e = threadIdx.x + u * TPB;
+                if (e < c_out * M) {
+                    const int m = e % M;
+                    for (int i = 0; i < c_in; ++i) {
+                        const float xr = S[i * KP + m], xi = S[i * KP + M + m];
+                        const float wr = a.wr[(size_t)i * slab + e], wi = a.wi[(size_t)i * slab + e];
+                        yr[u] = fmaf(xr, wr, fmaf(-xi, wi, yr[u]));
+                        yi[u] = fmaf(xr, wi, fmaf(xi, wr, yi[u]));
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < EPT; ++u) {
+            const int e = threadIdx.x + u * TPB;
+            if (e < c_out * M) {
+                const int o = e / M, m = e - o * M;
+                const float s = m == 0 ? s0 : s1;
+                Z[o * KP + m] = s * yr[u];
+                Z[o * KP + M + m] = s * yi[u];
+            }
         }
     } else {
         for (int i = threadIdx.x; i < c_in * K2; i += blockDim.x) {   // G = s (.) S, in place
@@ -141,27 +211,68 @@ __global__ void __launch_bounds__(TPB, 2) spec_conv_kernel(const Args a) {
                 dst[i] = S[c * KP + k];
             }
         }
-        for (int e = threadIdx.x; e < c_out * M; e += blockDim.x) {   // c_out = Cin of the forward operator
-            const int i = e / M, m = e - i * M;
-            float gr = 0.0f, gi = 0.0f;
-            const float* pr = a.wr + (size_t)i * a.cout * M + m;
-            const float* pi = a.wi + (size_t)i * a.cout * M + m;
-            for (int o0 = 0; o0 < c_in; o0 += 16) {
-                float wr[16], wi[16];
+        // GX[i][m] = sum_o G[o][m] * conj(W[i][o][m]); c_out = Cin, c_in = Cout of the forward operator.  The weights stream
+        // through the (dead) sample buffer in slabs of `ch` forward-output channels: for every i a contiguous run of ch * M
+        // floats at W[i][o0 .. o0 + ch][:]
+        int ch = 8;
+        while (ch > 1 && (2 * ch * M * c_out > c_in * NP || (c_in % ch))) ch >>= 1;
+        const int run = ch * M;                             // floats per i in a slab
+        const bool staged = 2 * run * c_out <= c_in * NP && !(run & 3);
+        float* wbuf_r = xs;
+        float* wbuf_i = xs + run * c_out;
+        constexpr int EPT = 4;
+        float gr[EPT], gi[EPT];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    wr[u] = pr[(size_t)(o0 + u) * M];
-                    wi[u] = pi[(size_t)(o0 + u) * M];
+        for (int u = 0; u < EPT; ++u) gr[u] = gi[u] = 0.0f;
+        if (staged) {
+            const int run4 = run >> 2;
+            for (int o0 = 0; o0 < c_in; o0 += ch) {
+                __syncthreads();
+                for (int j = threadIdx.x; j < c_out * run4; j += blockDim.x) {
+                    const int i = j / run4, t = j - i * run4;
+                    const size_t g4 = (((size_t)i * a.cout + o0) * M) / 4 + t;
+                    reinterpret_cast<float4*>(wbuf_r)[j] = reinterpret_cast<const float4*>(a.wr)[g4];
+                    reinterpret_cast<float4*>(wbuf_i)[j] = reinterpret_cast<const float4*>(a.wi)[g4];
                 }
+                __syncthreads();
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const float yr = S[(o0 + u) * KP + m], yi = S[(o0 + u) * KP + M + m];
-                    gr = fmaf(yr, wr[u], fmaf(yi, wi[u], gr));
-                    gi = fmaf(yi, wr[u], fmaf(-yr, wi[u], gi));
+                for (int u = 0; u < EPT; ++u) {
+                    const int e = threadIdx.x + u * TPB;
+                    if (e < c_out * M) {
+                        const int i = e / M, m = e - i * M;
+                        for (int c = 0; c < ch; ++c) {
+                            const float yr = S[(o0 + c) * KP + m], yi = S[(o0 + c) * KP + M + m];
+                            const float wr = wbuf_r[i * run + c * M + m], wi = wbuf_i[i * run + c * M + m];
+                            gr[u] = fmaf(yr, wr, fmaf(yi, wi, gr[u]));
+                            gi[u] = fmaf(yi, wr, fmaf(-yr, wi, gi[u]));
+                        }
+                    }
                 }
             }
-            Z[i * KP + m] = gr;
-            Z[i * KP + M + m] = gi;
+        } else {
+#pragma unroll
+            for (int u = 0; u < EPT; ++u) {
+                const int e = threadIdx.x + u * TPB;
+                if (e < c_out * M) {
+                    const int i = e / M, m = e - i * M;
+                    for (int o = 0; o < c_in; ++o) {
+                        const float yr = S[o * KP + m], yi = S[o * KP + M + m];
+                        const size_t wi_ = ((size_t)i * a.cout + o) * M + m;
+                        const float wr = a.wr[wi_], wi = a.wi[wi_];
+                        gr[u] = fmaf(yr, wr, fmaf(yi, wi, gr[u]));
+                        gi[u] = fmaf(yi, wr, fmaf(-yr, wi, gi[u]));
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < EPT; ++u) {
+            const int e = threadIdx.x + u * TPB;
+            if (e < c_out * M) {
+                const int i = e / M, m = e - i * M;
+                Z[i * KP + m] = gr[u];
+                Z[i * KP + M + m] = gi[u];
+            }
         }
     }
     __syncthreads();
@@ -174,24 +285,34 @@ __global__ void __launch_bounds__(TPB, 2) spec_conv_kernel(const Args a) {
             const int rt = t / ctiles, ct = t - rt * ctiles;
             const int pos = 16 * ct + r;
             const float* arow = Z + (16 * rt + r) * KP;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            for (int k0 = 0; k0 < K2; k0 += 4) {
-                const int k = k0 + q;
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[k], twiddle(tab, k, pos, M, nmask, quarter), acc, 0, 0, 0);
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            for (int k0 = 0; k0 < K2; k0 += 8) {     // 2 M is a multiple of 16
+                const int ka = k0 + q, kb = k0 + 4 + q;
+                const float a0 = arow[ka], a1 = arow[kb];
+                const float b0 = tw(ka, pos), b1 = tw(kb, pos);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc1, 0, 0, 0);
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) dst[(size_t)(16 * rt + 4 * q + j) * N + pos] = acc[j];
+            for (int j = 0; j < 4; ++j) dst[(size_t)(16 * rt + 4 * q + j) * N + pos] = acc0[j] + acc1[j];
         }
     }
 }
 
 int launch(void* stream, const Args& a, int b, const char* who) {
     const int c_in = a.backward ? a.cout : a.cin, c_out = a.backward ? a.cin : a.cout;
-    const size_t lds = sizeof(float) * ((size_t)c_in * (a.n + 4) + a.n + (size_t)(c_in + c_out) * (2 * a.m + 4));
+    const size_t kp = 2 * a.m + 4;
+    const size_t base = sizeof(float) * ((size_t)c_in * (a.n + 4) + (size_t)(c_in + c_out) * kp);
+    const size_t lds_dense = base + sizeof(float) * (size_t)a.n * kp, lds_table = base + sizeof(float) * (size_t)a.n;
+    const bool dense = lds_dense <= 160 * 1024 && (size_t)a.n <= (size_t)(c_in + c_out) * kp;
+    const size_t lds = dense ? lds_dense : lds_table;
     if (lds > 160 * 1024) return fail(-4, "%s: needs %zu B of LDS (> 160 KiB): channels x N too large", who, lds);
-    if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute((const void*)spec_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(spec_conv_kernel, dim3(b), dim3(TPB), lds, (hipStream_t)stream, a);
+    auto go = [&](auto kernel) {
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kernel, dim3(b), dim3(TPB), lds, (hipStream_t)stream, a);
+    };
+    if (dense) go(spec_conv_kernel<true>);
+    else go(spec_conv_kernel<false>);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(-2, "%s launch failed: %s", who, hipGetErrorString(e));
     return 0;
@@ -202,6 +323,8 @@ int check_geometry(const char* who, int b, int cin, int cout, int n, int modes) 
     if ((cin & 15) || (cout & 15)) return fail(-4, "%s: channel counts (%d, %d) must be multiples of 16", who, cin, cout);
     if (n < 32 || n > 2048 || (n & (n - 1))) return fail(-4, "%s: N = %d must be a power of two in [32, 2048]", who, n);
     if (modes <= 0 || (modes & 7) || 2 * modes >= n) return fail(-4, "%s: modes = %d must be a multiple of 8 below N/2", who, modes);
+    if (cin * modes > 4 * TPB || cout * modes > 4 * TPB)
+        return fail(-4, "%s: channels x modes (%d, %d) exceed %d mixing outputs per workgroup", who, cin * modes, cout * modes, 4 * TPB);
     return 0;
 }
 

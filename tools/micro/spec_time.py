@@ -1,0 +1,14 @@
+import os, sys, time
+sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "model-based-pde-control_amd"))
+import torch
+from pdecontrol.surrogates import spectral
+dev = torch.device("cuda", 0)
+x = torch.randn(64, 32, 512, device=dev); wr = torch.randn(32, 32, 16, device=dev); wi = torch.randn(32, 32, 16, device=dev)
+with torch.no_grad():
+    for _ in range(5): spectral.spectral_conv1d(x, wr, wi)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(50): spectral.spectral_conv1d(x, wr, wi)
+    e1.record(); torch.cuda.synchronize()
+print("SPEC_SKIP", os.environ.get("SPEC_SKIP", "0"), "us per call", e0.elapsed_time(e1) / 50 * 1e3)
