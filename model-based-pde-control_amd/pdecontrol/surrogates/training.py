@@ -256,10 +256,11 @@ class PDETrainingModule(pl.LightningModule):
         data.update({"l1_loss_rews": e1.numpy(), "l2_loss_rews": e2.numpy(), "l1_loss_scaled_rews": (e1 / r1).numpy(),
                      "l2_loss_scaled_rews": (e2 / r2).numpy(), "nrmse_rews": (e2 ** 2 / r2 ** 2).numpy()})
 
-        # spatial derivatives (env.rhs) of true vs predicted states
+        # spatial derivatives (env.rhs) of true vs predicted states.  The reference calls env.rhs once per sample
+        # (training.py:237-245); the HIP rhs hook is row-parallel, so all B*T samples go in ONE call (same values)
         def derivatives(vals):
-            d = [self.env.rhs(v, p)[1] for v, p in zip(vals.numpy(), phi.numpy())]
-            d = torch.as_tensor(np.asarray([list(x) for x in d]))
+            _, (ux, uxx, uxxxx) = self.env.rhs(vals.numpy(), phi.numpy())
+            d = torch.as_tensor(np.stack([ux, uxx, uxxxx], axis=1))            # [B*T, 3, C, H]
             return d.reshape(b, t, *d.shape[1:])
         dv, pdv = derivatives(flat(states, sc, sh)), derivatives(flat(outputs, sc, sh))
         d1, n1 = torch.norm(dv - pdv, p=1, dim=4), torch.norm(dv, p=1, dim=4)

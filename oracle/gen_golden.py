@@ -594,6 +594,45 @@ def wrapper_ks_fixtures():
     return rec
 
 
+def evalstep_fixtures(ks):
+    """validation_step (pdecontrol/surrogates/training.py:132-174) and test_step (:176-271) of the reference's
+    PDETrainingModule, with the reference's KS env (rhs / forcing / reward_func on the CPU) and the controller's
+    replay->world transforms (mbrl.py:146-187).  Every returned array is recorded."""
+    from pdecontrol.architectures.autoreg import KSAutoRegConvolutionalLSTM
+    from pdecontrol.surrogates.training import PDETrainingModule
+    import pdegym.common.transforms as T
+    env = ks.KuramotoSivashinskyEnv()
+    # transforms as the offline evaluation builds them (pdecontrol/surrogates/evaluation/evaluate.py:86-112)
+    rs = np.random.RandomState(21)
+    x = np.linspace(0, 2 * np.pi, 64, endpoint=False)
+    raw_states = np.stack([[np.sin(x + 0.2 * t + b) + 0.3 * np.cos(3 * x - 0.1 * t) for t in range(9)] for b in range(3)])
+    raw_states = raw_states.astype(np.float32).reshape(27, 1, 64)
+    raw_actions = rs.uniform(-1, 1, (27, 1, 4)).astype(np.float32)
+    oscaling = T.Normalize(aggregate=True, batched=True)
+    forcing = T.BatchTransform(env.forcing)
+    pdescaling = T.Normalize(aggregate=True, batched=True)
+    oscaling.update(raw_states)
+    pdescaling.update(forcing(raw_actions))
+    stransf = T.SampleTransform(oscaling, T.Operation([forcing, pdescaling]))
+    torch.manual_seed(0)
+    f = KSAutoRegConvolutionalLSTM()
+    sur = f.surrogate(delta=0.25, dscaling=None, tau=5, **f.model())
+    module = PDETrainingModule(surrogate=sur, loss=torch.nn.MSELoss(reduction="none"), tstep=0.25, delta=0.25, env=env,
+                               stransf=stransf, tau=5, tbtt=10)
+    states = torch.from_numpy(oscaling(raw_states)).reshape(3, 9, 1, 64)
+    actions = torch.from_numpy(pdescaling(forcing(raw_actions))).reshape(3, 9, 1, 64).to(torch.float32)
+    out_extra = {"raw_states": raw_states, "raw_actions": raw_actions}
+    out = {"states": states.numpy().copy(), "actions": actions.numpy().copy(), **out_extra}
+    with torch.no_grad():
+        val = module.validation_step((states, actions), 0)
+        tst = module.test_step((states, actions), 0)
+    for k, v in val.items():
+        out["val_" + k] = np.asarray(v.detach().numpy() if isinstance(v, torch.Tensor) else v).copy()
+    for k, v in tst.items():
+        out["test_" + k] = np.asarray(v.detach().numpy() if isinstance(v, torch.Tensor) else v).copy()
+    return out
+
+
 def burgers_fixtures():
     """the reference has no Burgers env; its discretisation lives in BurgersPhyPDELoss
     (pdecontrol/surrogates/phyloss/phyloss.py:36-86).  Record residual() and phyevolve() of that class on smooth and
@@ -678,7 +717,7 @@ def world_fixtures(ks):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-reset", action="store_true", help="skip the two ~50 s burn-in resets")
-    ap.add_argument("--only", choices=["ks", "surrogate", "surrogate256", "wrappers", "wrappers_ks", "dataset", "world", "burgers"], default=None)
+    ap.add_argument("--only", choices=["ks", "surrogate", "surrogate256", "wrappers", "wrappers_ks", "dataset", "world", "burgers", "evalstep"], default=None)
     args = ap.parse_args()
     if not os.path.isdir(REF):
         sys.exit("reference not present: fixtures can only be generated in the build container")
@@ -708,6 +747,12 @@ def main():
         fx = dataset_fixtures()
         np.savez_compressed(os.path.join(OUT, "dataset_golden.npz"), **fx)
         print("dataset_golden.npz:", len(fx), "arrays")
+    if args.only in (None, "evalstep"):
+        ksm = _load("pdegym.kuramoto.kuramoto", "pdegym/kuramoto/kuramoto.py")
+        import pdecontrol.surrogates.training  # noqa: F401
+        fx = evalstep_fixtures(ksm)
+        np.savez_compressed(os.path.join(OUT, "evalstep_golden.npz"), **fx)
+        print("evalstep_golden.npz:", len(fx), "arrays")
     if args.only in (None, "burgers"):
         fx = burgers_fixtures()
         np.savez_compressed(os.path.join(OUT, "burgers_golden.npz"), **fx)

@@ -283,3 +283,13 @@ def test_n256_benchmarked_batch_b64_fused():
         if p.requires_grad:
             ref = g["b64n_grad/" + k]
             np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=1e-2, atol=4e-5 * max(1.0, np.abs(ref).max()), err_msg=k)
+
+
+def test_validation_and_test_step_on_gpu_against_reference_module():
+    """validation_step / test_step with the module on the GPU (fused rollout) and env.rhs on the HIP hook (one batched call
+    for all samples) against the arrays the reference's module produced on the CPU."""
+    from pdegym.kuramoto import KuramotoSivashinskyEnv
+    from test_surrogate_host import build_eval_module, check_eval_steps
+    dev = torch.device("cuda", 0)
+    module, g = build_eval_module(KuramotoSivashinskyEnv(), dev)
+    check_eval_steps(module, g, dev, rtol=2e-4, atol=2e-5)

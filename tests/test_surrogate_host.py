@@ -1,5 +1,6 @@
 """Surrogate mirror (pdecontrol.*) on CPU against golden tensors captured from the reference.
 The CPU path is plain torch, i.e. the fp32 torch reference the GPU kernels are compared to."""
+import sys
 import os
 
 import numpy as np
@@ -261,3 +262,48 @@ def test_n256_factory_matches_reference_building_blocks():
         for k, p in m.surrogate.named_parameters():
             if p.grad is not None:
                 np.testing.assert_allclose(p.grad.numpy(), g[f"{tag}_grad/" + k], rtol=1e-5, atol=1e-7, err_msg=k)
+
+
+# ---- validation_step / test_step (pdecontrol/surrogates/training.py:132-271) against the reference's module -------------
+EVAL_GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "evalstep_golden.npz")
+
+
+def build_eval_module(env, device="cpu"):
+    """The offline-evaluation setup (pdecontrol/surrogates/evaluation/evaluate.py:86-164), as in
+    oracle/gen_golden.py::evalstep_fixtures, from this repo's classes."""
+    from pdegym.common import transforms as T
+    g = np.load(EVAL_GOLDEN)
+    oscaling = T.Normalize(aggregate=True, batched=True)
+    forcing = T.BatchTransform(env.forcing)
+    pdescaling = T.Normalize(aggregate=True, batched=True)
+    oscaling.update(g["raw_states"])
+    pdescaling.update(forcing(g["raw_actions"]))
+    stransf = T.SampleTransform(oscaling, T.Operation([forcing, pdescaling]))
+    torch.manual_seed(0)
+    f = KSAutoRegConvolutionalLSTM()
+    sur = f.surrogate(delta=0.25, dscaling=None, tau=5, **f.model())
+    module = PDETrainingModule(surrogate=sur, loss=torch.nn.MSELoss(reduction="none"), tstep=0.25, delta=0.25, env=env,
+                               stransf=stransf, tau=5, tbtt=10)
+    return module.to(device), g
+
+
+def check_eval_steps(module, g, device="cpu", rtol=1e-6, atol=1e-7):
+    s, a = torch.from_numpy(g["states"]).to(device), torch.from_numpy(g["actions"]).to(device)
+    with torch.no_grad():
+        val = module.validation_step((s, a), 0)
+        tst = module.test_step((s, a), 0)
+    for k, v in val.items():
+        np.testing.assert_allclose(np.asarray(v.detach().cpu().numpy()), g["val_" + k], rtol=rtol, atol=atol, err_msg="val " + k)
+    assert sorted("test_" + k for k in tst) == sorted(k for k in g.files if k.startswith("test_"))
+    for k, v in tst.items():
+        np.testing.assert_allclose(np.asarray(v), g["test_" + k], rtol=rtol, atol=atol, err_msg="test " + k)
+
+
+def test_validation_and_test_step_match_reference_module():
+    """Every array validation_step / test_step return (losses per horizon step, scaled errors, reward errors, errors of
+    the three spatial derivatives from env.rhs) against the reference module's, env.rhs on the oracle-backed stepper."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _oracle_stepper import OracleStepper
+    from pdegym.kuramoto import KuramotoSivashinskyEnv
+    module, g = build_eval_module(KuramotoSivashinskyEnv(_stepper_cls=OracleStepper))
+    check_eval_steps(module, g)
