@@ -56,9 +56,12 @@ except ImportError:
         def __init__(self, max_steps=-1, max_epochs=1, gradient_clip_val=None, **kwargs):
             self.max_steps, self.max_epochs, self.gradient_clip_val = max_steps, max_epochs, gradient_clip_val
             self.global_step = 0
+            self.current_epoch = 0
             self.callback_metrics = {}
 
         def fit(self, module, train_dataloaders=None, datamodule=None):
+            if datamodule is not None:
+                datamodule.trainer = self        # the datamodule reads current_epoch / global_step (curriculum)
             loader = train_dataloaders if train_dataloaders is not None else datamodule.train_dataloader()
             optimizers, schedulers = module.configure_optimizers()
             opt = optimizers[0]
@@ -86,6 +89,9 @@ except ImportError:
                 else:
                     for s in schedulers:
                         s["scheduler"].step()
+                self.current_epoch += 1
+                if datamodule is not None and train_dataloaders is None:
+                    loader = datamodule.train_dataloader()   # reload_dataloaders_every_n_epochs=1 (mbrl.py:361)
 
     pl = types.SimpleNamespace(LightningModule=LightningModule, LightningDataModule=LightningDataModule,
                                Callback=Callback, Trainer=Trainer,

@@ -58,6 +58,20 @@ class SubSeqDataset(Dataset):
         offset = index[key - 1] if key - 1 >= 0 else 0
         return self.subsamples[key], (idx - offset) * stride + self.lower
 
+    def locate_many(self, idxs):
+        """``locate`` for a whole batch of item indices at once (numpy ``searchsorted(side="right")`` is ``bisect_right``):
+        returns (episode keys [list], first steps [int64 array])."""
+        idxs = np.asarray(idxs, dtype=np.int64)
+        assert idxs.size == 0 or idxs.max() < len(self)
+        if self.bootstrapping:
+            idxs, index, stride = self.boots_mapping[idxs].astype(np.int64), self.boots_index, 1
+        else:
+            index, stride = self.index, self.stride
+        index = np.asarray(index, dtype=np.int64)
+        keys = np.searchsorted(index, idxs, side="right")
+        offsets = np.where(keys > 0, index[np.maximum(keys - 1, 0)], 0)
+        return [self.subsamples[k] for k in keys], (idxs - offsets) * stride + self.lower
+
     def __getitem__(self, idx):
         bidx, sidx = self.locate(idx)
         window = lambda store, dt: np.asarray(list(islice(store[bidx], sidx, sidx + self.length)), dtype=dt)
@@ -165,11 +179,34 @@ class DeviceSubSeqStore:
         self.tensors = tuple(pack(store, dt) for store, dt in zip(fields, _DTYPES))
 
     def batch(self, dataset: SubSeqDataset, indices, stransf=None):
-        located = [dataset.locate(int(i)) for i in indices]
-        first = np.asarray([self.starts[k] + s for k, s in located], dtype=np.int64)
+        keys, starts = dataset.locate_many(indices)
+        first = np.asarray([self.starts[k] for k in keys], dtype=np.int64) + starts
         rows = torch.from_numpy((first[:, None] + np.arange(dataset.length)[None, :]).reshape(-1)).to(self.device)
-        shape = (len(located), dataset.length)
+        shape = (len(keys), dataset.length)
         out = [t.index_select(0, rows).reshape(shape + tuple(t.shape[1:])) for t in self.tensors]
         out[6] = out[6].to(torch.int32)
         sample = Sample(*out)
         return stransf(sample) if stransf is not None else sample
+
+
+class DeviceBatchLoader:
+    """What ``PDEDataLoader(dataset, batch_size, shuffle=False, collate_fn=PDEDataLoader.sample_collate)`` yields -- the
+    loader the reference's datamodule builds (pdecontrol/surrogates/common/datamodule.py:66-72) -- assembled in HBM: the
+    same windows in the same order (the index stream of an unshuffled loader is 0, 1, 2, ...; the bootstrap resampling
+    lives in the dataset), one gather per field per batch from the packed replay, the dataset's ``stransf`` applied to
+    the whole device batch.  Batches are lists of device tensors in ``Sample`` field order, like ``default_collate``'s."""
+
+    def __init__(self, dataset: SubSeqDataset, store: DeviceSubSeqStore, batch_size: int, drop_last: bool = False):
+        self.dataset, self.store, self.batch_size, self.drop_last = dataset, store, int(batch_size), drop_last
+
+    def __len__(self):
+        n = len(self.dataset)
+        return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        n = int(len(self.dataset))
+        for i0 in range(0, n, self.batch_size):
+            i1 = min(i0 + self.batch_size, n)
+            if self.drop_last and i1 - i0 < self.batch_size:
+                return
+            yield list(self.store.batch(self.dataset, np.arange(i0, i1), stransf=self.dataset.stransf))

@@ -82,3 +82,58 @@ def test_datamodule_curriculum_window():
     assert next(iter(dm.test_dataloader()))[0].shape[1] == 4
     dm.iteration = 4
     assert next(iter(dm.val_dataloader()))[0].shape[1] == 2 + 3
+
+
+def test_locate_many_is_locate():
+    _, rp = sc.run(ExperienceReplay, ds, sched, Sample)
+    for bootstrapping, stride in ((False, 2), (False, None), (True, 1)):
+        np.random.seed(5)
+        d = ds.SubSeqDataset(rp.data, length=3, stride=stride, bootstrapping=bootstrapping, bounds=(1, 0))
+        idx = np.arange(len(d))
+        keys, starts = d.locate_many(idx)
+        one_by_one = [d.locate(int(i)) for i in idx]
+        assert keys == [k for k, _ in one_by_one]
+        np.testing.assert_array_equal(starts, [s for _, s in one_by_one])
+    assert d.locate_many([])[0] == []
+
+
+def _datamodule_batches(device_data):
+    from pdecontrol.surrogates.common.datamodule import PDEDataModule
+    from pdegym.common.transforms import BatchTransform, Normalize, SampleTransform
+    _, rp = sc.run(ExperienceReplay, ds, sched, Sample)
+    norm = Normalize(aggregate=True, batched=True)
+    norm.mean, norm.var = torch.full((1, 1, 1), 0.2), torch.full((1, 1, 1), 1.5)
+    dm = PDEDataModule(rp.data, train=rp.episodes, val=rp.episodes[:1], test=rp.episodes[:1], bootstrapping=True,
+                       stransf=SampleTransform(otransf=BatchTransform(norm)), tau=2, target_length=2, batch_size=3,
+                       device_data=device_data)
+
+    class T:
+        current_epoch, global_step = 0, 0
+    dm.trainer = T()
+    out = []
+    for make in (dm.train_dataloader, dm.val_dataloader, dm.test_dataloader):
+        np.random.seed(9)                      # the bootstrap mapping is drawn when the dataset is built
+        out.append([[t.cpu() for t in batch] for batch in make()])
+    return out
+
+
+def check_device_loader(device):
+    host, dev = _datamodule_batches(None), _datamodule_batches(device)
+    for h_loader, d_loader in zip(host, dev):
+        assert len(h_loader) == len(d_loader) > 0
+        for hb, db in zip(h_loader, d_loader):       # incl. the ragged last batch
+            assert len(hb) == len(db) == 7
+            for h, d in zip(hb, db):
+                assert h.shape == d.shape and h.dtype == d.dtype
+                torch.testing.assert_close(d, h, rtol=0, atol=0)
+
+
+def test_device_batch_loader_equals_host_loader():
+    """PDEDataModule(device_data=...) yields the batches the reference-style host loader yields (same windows, order,
+    dtypes, transform applied), here with the store on the CPU device."""
+    check_device_loader("cpu")
+
+
+@pytest.mark.gpu
+def test_device_batch_loader_on_gpu():
+    check_device_loader("cuda:0")

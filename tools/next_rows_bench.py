@@ -84,6 +84,38 @@ dt_dev = (time.perf_counter() - t0) / 20
 out["f3_batch_assembly"] = {"B": B, "T": 20, "replay_steps": rp.ntimesteps, "host_loader_ms": dt_host * 1e3,
                             "device_store_ms": dt_dev * 1e3, "speedup": dt_host / dt_dev}
 
+# end to end: Trainer.fit over PDEDataModule (host loader vs device_data) driving the graphed TBPTT step
+from pdecontrol._compat.lightning import pl  # noqa: E402
+from pdecontrol.surrogates.bench_tbptt import build_module  # noqa: E402
+from pdecontrol.surrogates.common.datamodule import PDEDataModule  # noqa: E402
+
+
+def fit_rate(device_data):
+    np.random.seed(0)
+    dm = PDEDataModule(rp.data, train=list(rp.obs.keys()), bootstrapping=True, tau=5, batch_size=B, device_data=device_data,
+                       curriculum=None)
+    dm.curriculum = lambda *a: 15                      # window = tau + 15 = 20 steps, the README setting
+    module = build_module(dev, graphed=True)
+    if device_data is None:                            # host batches must be moved to the module's device, as Lightning does
+        step = module.training_step
+        module.training_step = lambda batch, i: step([t.to(dev, non_blocking=True) for t in batch], i)
+    tr = pl.Trainer(max_steps=20, max_epochs=1)
+    dm.trainer = tr
+    tr.fit(module, datamodule=dm)                      # warm-up: capture
+    torch.cuda.synchronize()
+    tr = pl.Trainer(max_steps=100, max_epochs=1)
+    dm.trainer = tr
+    t0 = time.perf_counter()
+    tr.fit(module, datamodule=dm)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / tr.global_step
+
+
+dt_fit_host, dt_fit_dev = fit_rate(None), fit_rate("cuda:0")
+out["f3_fit_loop"] = {"B": B, "T": 20, "N": 64, "what": "Trainer.fit (shim) over PDEDataModule driving the graphed TBPTT step",
+                      "ms_per_step_host_loader": dt_fit_host * 1e3, "ms_per_step_device_data": dt_fit_dev * 1e3,
+                      "seqs_per_s_device_data": B / dt_fit_dev}
+
 # ---- f2: imagined rollouts, 100 envs x horizon 5, CPU vs GPU fused -------------------------------------
 import _world_scenario  # noqa: E402,F401
 from test_world_env import namespace  # noqa: E402
