@@ -171,7 +171,11 @@ class PDETrainingModule(pl.LightningModule):
         key = (tuple(states.shape), tuple(actions.shape))
         cache = self.__dict__.setdefault("_graphed_steps", {})
         if key not in cache:
-            cache[key] = GraphedTBPTTStep(self, key[0], key[1], lr=lr)
+            # one process per GPU with an initialised process group: the captured step must exchange gradients
+            # (forward/backward graph -> one flat-bucket all-reduce -> Adam graph), never train the ranks apart silently
+            dist = torch.distributed
+            distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+            cache[key] = GraphedTBPTTStep(self, key[0], key[1], lr=lr, distributed=distributed)
         self.__dict__["_last_graphed_step"] = cache[key]
         return cache[key].step(states, actions, lr=lr)
 
