@@ -84,6 +84,9 @@ void fill_args(const ks_handle* h, ks::StepArgs& a) {
     a.dx = dx;
     a.dx2 = dx * dx;          // python: self.dx**2
     a.dx4 = std::pow(dx, 4.0);  // python: self.dx**4
+    a.r_dx = 1.0 / a.dx;        // IEEE divisions on the host: correctly rounded reciprocals
+    a.r_dx2 = 1.0 / a.dx2;
+    a.r_dx4 = 1.0 / a.dx4;
     // merged linear stencil  -(u_xxxx + u_xx):  c_k = -(D4_k/dx^4 + D2_k/dx^2)
     const double d2[5] = {-49.0 / 18, 3.0 / 2, -3.0 / 20, 1.0 / 90, 0.0};
     const double d4[5] = {91.0 / 8, -122.0 / 15, 169.0 / 60, -2.0 / 5, 7.0 / 240};

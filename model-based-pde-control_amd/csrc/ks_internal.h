@@ -24,8 +24,9 @@ struct StepArgs {
     double hdt, dt6, dt3;  // dt/2, dt/6, dt/3
     // both modes
     double dt;
-    // exact mode
+    // exact mode: the reference's divisors and their correctly rounded reciprocals (div_const in ks_kernels.hip)
     double dx, dx2, dx4;
+    double r_dx, r_dx2, r_dx4;
 };
 
 struct Layout {

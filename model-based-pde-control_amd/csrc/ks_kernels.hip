@@ -154,6 +154,21 @@ struct Halo<64, HALO_HYBRID1> : Halo<64, HALO_HYBRID> {
     }
 };
 
+// x / d for a divisor d that is constant over the launch, bit-identical to the IEEE division the reference performs:
+//   q = RN(x * r),  e = x - d * q (exact in one FMA),  result = RN(q + e * r),   r = RN(1 / d) from the host
+// (Markstein's correction step: with a correctly rounded reciprocal one step from the faithful q lands on the correctly
+// rounded quotient).  3 VALU instructions instead of the ~11 of the generic fp64 division sequence (v_div_scale x 2, v_rcp,
+// 5 FMA, v_div_fmas, v_div_fixup) -- the exact mode spends 17 divisions per point and sub-step, 47 % of its instructions.
+// Checked bit for bit against x / d on 7e9 dividends incl. ones placed next to rounding boundaries
+// (tools/micro/markstein_check.c) and, end to end, by the golden tests (200 000-sub-step reset, bit-identical state).
+// Not covered: x = -0.0 (gives +0.0; unreachable -- every dividend here is a sum whose coefficients have both signs, so a
+// vanishing sum is +0.0) and non-finite x (the env raises FloatingPointError on those anyway).
+__device__ __forceinline__ double div_const(double x, double d, double r) {
+    const double q = x * r;
+    const double e = __builtin_fma(-d, q, x);
+    return __builtin_fma(e, r, q);
+}
+
 // ------------------------------------------------------------------------------------------
 // rhs at one grid point.  w[] is the lane's window of u (4 halo + P + 4 halo), q[] = w[]^2,
 // c the index of the point inside the window.
@@ -173,20 +188,20 @@ __device__ __forceinline__ double rhs_point(const double* w, const double* q, in
         bwd += q[c - 2] * 3.0;
         bwd += q[c - 1] * (-4.0);
         bwd += q[c] * (25.0 / 12);
-        const double f = fwd / a.dx, b = bwd / a.dx;
+        const double f = div_const(fwd, a.dx, a.r_dx), b = div_const(bwd, a.dx, a.r_dx);
         const double u = w[c];
         const double d1 = (u < 0.0 ? 1.0 : 0.0) * f + (u >= 0.0 ? 1.0 : 0.0) * b;
         double d2 = u * (-49.0 / 18);
         d2 += (w[c - 3] + w[c + 3]) * (1.0 / 90);
         d2 += (w[c - 2] + w[c + 2]) * (-3.0 / 20);
         d2 += (w[c - 1] + w[c + 1]) * (3.0 / 2);
-        d2 = d2 / a.dx2;
+        d2 = div_const(d2, a.dx2, a.r_dx2);
         double d4 = u * (91.0 / 8);
         d4 += (w[c - 4] + w[c + 4]) * (7.0 / 240);
         d4 += (w[c - 3] + w[c + 3]) * (-2.0 / 5);
         d4 += (w[c - 2] + w[c + 2]) * (169.0 / 60);
         d4 += (w[c - 1] + w[c + 1]) * (-122.0 / 15);
-        d4 = d4 / a.dx4;
+        d4 = div_const(d4, a.dx4, a.r_dx4);
         return ((-d4 - d2) - 0.5 * d1) + phi;
     } else {
         double lin = __builtin_fma(a.c_lin[0], w[c], phi);
@@ -505,7 +520,7 @@ __global__ void __launch_bounds__(256) ks_rk4_fused(const StepArgs a) {
             const double k = kk[j];
             if constexpr (EXACT) {
                 acc[j] = acc[j] + k;
-                u[j] = u[j] + a.dt * acc[j] / 6.0;
+                u[j] = u[j] + div_const(a.dt * acc[j], 6.0, 1.0 / 6.0);
             } else {
                 u[j] = __builtin_fma(a.dt6, k, acc[j]);
             }
@@ -593,7 +608,7 @@ __global__ void __launch_bounds__(256) ks_rk4_lds(const StepArgs a) {
                     if (stage == 0) { ACC[i] = k; dst[i] = u0 + a.dt * k / 2.0; }
                     else if (stage == 1) { ACC[i] = ACC[i] + 2.0 * k; dst[i] = u0 + a.dt * k / 2.0; }
                     else if (stage == 2) { ACC[i] = ACC[i] + 2.0 * k; dst[i] = u0 + a.dt * k; }
-                    else { const double s4 = ACC[i] + k; dst[i] = u0 + a.dt * s4 / 6.0; }
+                    else { const double s4 = ACC[i] + k; dst[i] = u0 + div_const(a.dt * s4, 6.0, 1.0 / 6.0); }
                 } else {
                     if (stage == 0) { ACC[i] = __builtin_fma(a.dt6, k, u0); dst[i] = __builtin_fma(a.hdt, k, u0); }
                     else if (stage == 1) { ACC[i] = __builtin_fma(a.dt3, k, ACC[i]); dst[i] = __builtin_fma(a.hdt, k, u0); }
