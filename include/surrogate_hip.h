@@ -190,6 +190,16 @@ int sur_tbptt_delta_loss(void* stream, const float* states, long states_bstride,
                          float stdv, float* deltas, float* dd_all, float* hsteploss, float* loss, float* stats,
                          double* partial, unsigned int* ticket);
 
+/* The same loss over the time steps [t_begin, t_end) of the T rows only: the launches of one loss -- e.g. one per TBPTT
+ * chunk, issued as soon as that chunk's predictions exist, on any streams and in any order -- must cover [0, T) exactly
+ * once between them; `loss`, `hsteploss` and `stats` are written by whichever launch finishes last (the ticket counts
+ * the workgroups of all T rows), `deltas` / `dd_all` rows by the launch that covers them.  Lets the backward pass of an
+ * early chunk start while later chunks are still rolling out (training.py:71-121: gradients are cut between chunks). */
+int sur_tbptt_delta_loss_range(void* stream, const float* states, long states_bstride, long states_tstride, const float* d_all,
+                               int b, int t, int n, float delta, float mean, float stdv, float* deltas, float* dd_all,
+                               float* hsteploss, float* loss, float* stats, double* partial, unsigned int* ticket, int t_begin,
+                               int t_end);
+
 const char* sur_last_error(void);
 
 #ifdef __cplusplus

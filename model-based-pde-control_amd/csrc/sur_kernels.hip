@@ -32,7 +32,7 @@
 // Diagnostic build only (-DSUR_STAMP): shader-clock stamps per phase for workgroup 0 of each launch,
 // accumulated in a __device__ buffer nothing else reads (guide section 7, In-kernel stamps).
 #ifdef SUR_STAMP
-__device__ long long sur_stamp_buf[64];
+__device__ long long sur_stamp_buf[128];
 __device__ long long sur_stamp_last;
 #define STAMP(id)                                                                 \
     do {                                                                          \
@@ -628,18 +628,30 @@ __device__ void rb_forward(const RBBuf& b, const float* const* w) {
 
 // dout [cout][hout] -> din [cin][hin]; g1, g2, g3, xh: scratch of cout*hout floats each
 __device__ void rb_backward(const RBBuf& b, const float* const* w, float* const* g, const float* dout, float* din,
-                            float* g1, float* g2, float* g3, float* xh) {
+                            float* g1, float* g2, float* g3, float* xh, int sb = -1) {
+#ifdef SUR_STAMP
+#define RB_STAMP(i) do { if (sb >= 0) STAMP(sb + (i)); } while (0)
+#else
+#define RB_STAMP(i) do { } while (0)
+#endif
     act_ln_bwd(dout, b.s, b.cout, b.hout, w[SUR_RB_LN3_W], false, g1, xh, g[SUR_RB_LN3_W], g[SUR_RB_LN3_B]);
+    RB_STAMP(0);
     // skip path
     conv_bwd_weight<1>(g1, b.cout, b.in, b.cin, b.hin, b.stride, 0, g[SUR_RB_SKIP], nullptr, lower_half(), false);
     conv_bwd_data<1>(g1, b.cout, b.hin, w[SUR_RB_SKIP], b.cin, b.stride, 0, din, false, upper_half(), true);
+    RB_STAMP(1);
     // residual path
     act_ln_bwd(g1, b.a2pre, b.cout, b.hout, w[SUR_RB_LN2_W], true, g2, xh, g[SUR_RB_LN2_W], g[SUR_RB_LN2_B]);
+    RB_STAMP(2);
     conv_bwd_weight<3>(g2, b.cout, b.a1, b.cout, b.hout, 1, 1, g[SUR_RB_CONV2], nullptr, lower_half(), false);
     conv_bwd_data<3>(g2, b.cout, b.hout, w[SUR_RB_CONV2], b.cout, 1, 1, g3, false, upper_half(), true);
+    RB_STAMP(3);
     act_ln_bwd(g3, b.a1pre, b.cout, b.hout, w[SUR_RB_LN1_W], true, g1, xh, g[SUR_RB_LN1_W], g[SUR_RB_LN1_B]);
+    RB_STAMP(4);
     conv_bwd_weight<3>(g1, b.cout, b.in, b.cin, b.hin, b.stride, 1, g[SUR_RB_CONV1], nullptr, lower_half(), false);
     conv_bwd_data<3>(g1, b.cout, b.hin, w[SUR_RB_CONV1], b.cin, b.stride, 1, din, true, upper_half(), true);
+    RB_STAMP(5);
+#undef RB_STAMP
 }
 
 struct EncLayout {
@@ -905,11 +917,15 @@ __device__ __forceinline__ void enc_block_bwd_body(const EncBlockJob& j, int blk
     float* g3 = rb.s;     // likewise s
     float* din = cur; cur += nin;
     ParamViews<SUR_RB_NPARAM> v;
+    const int sbase = 64 + 16 * blk;   // SUR_STAMP ids of this block's phases
+    (void)sbase;
+    STAMP(sbase + 0);
     stage_weights<SUR_RB_NPARAM>(p.w + SUR_RB_NPARAM * blk, p.size + SUR_RB_NPARAM * blk, cur, v);
     const int psize = psize_of<SUR_ENC_NPARAM>(p.size);
     float* row = p.partial + (size_t)(j.row_base + wg) * psize + gm.param_off;
     float* gacc = j.grads_in_lds ? cur + gm.psize_blk : row;
     setup_grads<SUR_RB_NPARAM>(p.size + SUR_RB_NPARAM * blk, gacc, j.grads_in_lds != 0, v);
+    STAMP(sbase + 1);
     const int nsv = enc_saved_floats(p), nws = enc_ws_floats(p);
     const int h1 = p.n / p.stride[0];
     const int ws_in_off = blk == 2 ? p.c[1] * h1 : 0;       // where this block writes d loss / d its input (blocks 2, 1)
@@ -923,14 +939,17 @@ __device__ __forceinline__ void enc_block_bwd_body(const EncBlockJob& j, int blk
         lds_load_v4(rb.s, rec + gm.saved_off + 5 * a, a >> 2);
         const float* dsrc = blk == 2 ? j.dz + (size_t)m * a : j.ws + (size_t)m * nws + (blk == 1 ? ws_out_off : 0);
         lds_load_v4(dout, dsrc, a >> 2);
-        rb_backward(rb, v.w, v.g, dout, din, g1, g2, g3, xh);
+        STAMP(sbase + 2);
+        rb_backward(rb, v.w, v.g, dout, din, g1, g2, g3, xh, sbase + 3);
         if (blk > 0) {
             float* dst = j.ws + (size_t)m * nws + (blk == 2 ? ws_in_off : 0);
             for (int i = threadIdx.x; i < nin; i += blockDim.x) dst[i] = din[i];
         }
         __syncthreads();
+        STAMP(sbase + 9);
     }
     if (j.grads_in_lds) add_to_row(row, gacc, gm.psize_blk);
+    STAMP(sbase + 10);
 }
 
 #ifndef ENC_BLK_OCC
@@ -1014,12 +1033,14 @@ __global__ void __launch_bounds__(TPB)
 delta_loss_kernel(const float* __restrict__ states, long sb, long st, const float* __restrict__ d_all, int B, int T, int N, float delta,
                   float mean, float stdv, float* __restrict__ deltas, float* __restrict__ dd_all,
                   float* __restrict__ hsteploss, float* __restrict__ loss, float* __restrict__ stats,
-                  double* __restrict__ partial, unsigned int* __restrict__ ticket) {
+                  double* __restrict__ partial, unsigned int* __restrict__ ticket, int t0) {
     __shared__ double red[TPB / 64][LOSS_NSUM];
     __shared__ bool last;
     // blockIdx.x = time step, blockIdx.y = slice of the B*N elements of that step; LOSS_UNROLL elements per
     // thread per round with every load of the round issued before the first use
-    const int t = blockIdx.x, per_t = B * N, nsplit = gridDim.y;
+    // a launch covers the time steps [t0, t0 + gridDim.x) of the T rows; the ticket counts the workgroups of ALL T rows, so
+    // the launches of one loss (one per TBPTT chunk, in any order, on any streams) share the final reduction
+    const int t = t0 + blockIdx.x, per_t = B * N, nsplit = gridDim.y;
     const double count = (double)per_t * (T - 1);
     double acc[LOSS_NSUM] = {0.0, 0.0, 0.0, 0.0, 0.0};
     const int stride = nsplit * TPB;
@@ -1068,7 +1089,7 @@ delta_loss_kernel(const float* __restrict__ states, long sb, long st, const floa
     }
     __threadfence();
     __syncthreads();
-    if (threadIdx.x == 0) last = (atomicAdd(ticket, 1u) == (unsigned)(gridDim.x * gridDim.y - 1));
+    if (threadIdx.x == 0) last = (atomicAdd(ticket, 1u) == (unsigned)(T * nsplit - 1));
     __syncthreads();
     if (!last) return;
     __threadfence();
@@ -1917,10 +1938,10 @@ extern "C" {
 const char* sur_last_error(void) { return g_err; }
 
 #ifdef SUR_STAMP
-int sur_debug_stamps(long long* out64, int reset) {
-    if (out64 && hipMemcpyFromSymbol(out64, HIP_SYMBOL(sur_stamp_buf), sizeof(long long) * 64) != hipSuccess) return -2;
+int sur_debug_stamps(long long* out128, int reset) {
+    if (out128 && hipMemcpyFromSymbol(out128, HIP_SYMBOL(sur_stamp_buf), sizeof(long long) * 128) != hipSuccess) return -2;
     if (reset) {
-        long long z[64] = {0};
+        long long z[128] = {0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(sur_stamp_buf), z, sizeof(z)) != hipSuccess) return -2;
     }
     return 0;
@@ -2311,21 +2332,38 @@ int sur_adam_apply(void* stream, const sur_encoder_params* e0, const sur_adam* a
     }, "adam_all");
 }
 
+static int delta_loss_launch(void* stream, const float* states, long states_bstride, long states_tstride, const float* d_all, int b,
+                             int t, int n, float delta, float mean, float stdv, float* deltas, float* dd_all, float* hsteploss,
+                             float* loss, float* stats, double* partial, unsigned int* ticket, int t_begin, int t_end,
+                             const char* who) {
+    if (!states || !d_all || !deltas || !hsteploss || !loss || !stats || !partial || !ticket || b <= 0 || t < 2 || n <= 0)
+        return fail(-1, "%s: bad argument (need B > 0, T >= 2, N > 0)", who);
+    if (t_begin < 0 || t_end > t || t_begin >= t_end) return fail(-1, "%s: time range [%d, %d) outside [0, %d)", who, t_begin, t_end, t);
+    if (states_bstride < n || states_tstride < n) return fail(-1, "%s: state strides must be at least N", who);
+    if (!(delta != 0.0f) || !(stdv > 0.0f)) return fail(-1, "%s: delta must be non-zero and std positive", who);
+    int nsplit = (b * n + LOSS_UNROLL * TPB - 1) / (LOSS_UNROLL * TPB);
+    nsplit = nsplit < 1 ? 1 : (nsplit > LOSS_MAX_SPLIT ? LOSS_MAX_SPLIT : nsplit);
+    return launch_checked([&] {
+        hipLaunchKernelGGL(delta_loss_kernel, dim3(t_end - t_begin, nsplit), dim3(TPB), 0, (hipStream_t)stream, states, states_bstride,
+                           states_tstride, d_all, b, t, n, delta, mean,
+                           stdv, deltas, dd_all, hsteploss, loss, stats, partial, ticket, t_begin);
+    }, "delta_loss");
+}
+
 int sur_tbptt_delta_loss(void* stream, const float* states, long states_bstride, long states_tstride, const float* d_all, int b,
                          int t, int n, float delta, float mean,
                          float stdv, float* deltas, float* dd_all, float* hsteploss, float* loss, float* stats,
                          double* partial, unsigned int* ticket) {
-    if (!states || !d_all || !deltas || !hsteploss || !loss || !stats || !partial || !ticket || b <= 0 || t < 2 || n <= 0)
-        return fail(-1, "sur_tbptt_delta_loss: bad argument (need B > 0, T >= 2, N > 0)");
-    if (states_bstride < n || states_tstride < n) return fail(-1, "sur_tbptt_delta_loss: state strides must be at least N");
-    if (!(delta != 0.0f) || !(stdv > 0.0f)) return fail(-1, "sur_tbptt_delta_loss: delta must be non-zero and std positive");
-    int nsplit = (b * n + LOSS_UNROLL * TPB - 1) / (LOSS_UNROLL * TPB);
-    nsplit = nsplit < 1 ? 1 : (nsplit > LOSS_MAX_SPLIT ? LOSS_MAX_SPLIT : nsplit);
-    return launch_checked([&] {
-        hipLaunchKernelGGL(delta_loss_kernel, dim3(t, nsplit), dim3(TPB), 0, (hipStream_t)stream, states, states_bstride,
-                           states_tstride, d_all, b, t, n, delta, mean,
-                           stdv, deltas, dd_all, hsteploss, loss, stats, partial, ticket);
-    }, "delta_loss");
+    return delta_loss_launch(stream, states, states_bstride, states_tstride, d_all, b, t, n, delta, mean, stdv, deltas, dd_all,
+                             hsteploss, loss, stats, partial, ticket, 0, t, "sur_tbptt_delta_loss");
+}
+
+int sur_tbptt_delta_loss_range(void* stream, const float* states, long states_bstride, long states_tstride, const float* d_all,
+                               int b, int t, int n, float delta, float mean, float stdv, float* deltas, float* dd_all,
+                               float* hsteploss, float* loss, float* stats, double* partial, unsigned int* ticket, int t_begin,
+                               int t_end) {
+    return delta_loss_launch(stream, states, states_bstride, states_tstride, d_all, b, t, n, delta, mean, stdv, deltas, dd_all,
+                             hsteploss, loss, stats, partial, ticket, t_begin, t_end, "sur_tbptt_delta_loss_range");
 }
 
 }  // extern "C"

@@ -24,6 +24,7 @@ process aborts.  ``capture_graph`` therefore collects before the capture and kee
 warm-up and capture run on the same explicit stream, and only detached tensors are kept from the captured step.
 """
 import gc
+import os
 
 import torch
 
@@ -111,11 +112,14 @@ def shared_state(module, lr=None):
 class GraphedTBPTTStep:
     """``step()`` replays one optimizer step of ``module`` for one batch shape."""
 
-    def __init__(self, module, batch_shape, action_shape=None, lr=None, distributed=False, warmup=3, capture=True):
+    def __init__(self, module, batch_shape, action_shape=None, lr=None, distributed=False, warmup=3, capture=True,
+                 pipelined=None):
         """module: PDETrainingModule on a CUDA device; batch_shape: [B, T, 1, N] of states.
         capture=False prepares everything (static buffers, warmed-up kernels, optimizer state) but leaves
         the capture to the caller (EnsembleTBPTTStep records several members into one graph)."""
         self.module = module
+        # pipelined: chunk c's backward beside chunk c+1's forward (hipops.fused_tbptt_train); PDECONTROL_PIPELINED=0 opts out
+        self.pipelined = (os.environ.get("PDECONTROL_PIPELINED", "1") != "0") if pipelined is None else bool(pipelined)
         dev = next(module.surrogate.parameters()).device
         assert dev.type == "cuda", "HIP graphs need the module on a GPU"
         self.device = dev
@@ -154,6 +158,11 @@ class GraphedTBPTTStep:
     def _fwd_bwd(self):
         if not self.adam_in_flush:
             self.bucket.zero_()
+        if self.pipelined and self._fused():
+            # forward, loss, backward and gradient reduction hand-scheduled with the TBPTT chunks pipelined (no autograd)
+            out = self.module._pipelined_training_step((self.states, self.actions))
+            if out is not None:
+                return _detached(out)
         out = self.module._eager_training_step((self.states, self.actions), 0)
         if self._fused():
             from pdecontrol.surrogates import hipops

@@ -14,6 +14,8 @@ There is no fallback in here: if the library is missing, ``load()`` raises.
 import ctypes
 import os
 
+import types
+
 import torch
 from torch import nn
 
@@ -73,6 +75,8 @@ SYMBOLS = (
     ("sur_adam_apply", [_fp, _EP, _AP, _EP, _AP, _CP, _AP]),
     ("sur_tbptt_delta_loss", [_fp, _fp, ctypes.c_long, ctypes.c_long, _fp, _i, _i, _i, ctypes.c_float, ctypes.c_float, ctypes.c_float, _fp, _fp, _fp, _fp,
                               _fp, _fp, _fp]),
+    ("sur_tbptt_delta_loss_range", [_fp, _fp, ctypes.c_long, ctypes.c_long, _fp, _i, _i, _i, ctypes.c_float, ctypes.c_float,
+                                    ctypes.c_float, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i]),
 )
 _lib = None
 
@@ -796,8 +800,14 @@ class _Fork:
     capture (the side work becomes a parallel branch of the graph).  With ``inner_forks(False)`` the block
     simply runs on the current stream."""
 
-    def __init__(self, stream, worthwhile=True):
+    def __init__(self, stream, worthwhile=True, after=None):
+        """``after``: an event recorded earlier on the current stream = the fork point (default: now).  Recording the
+        fork point first and entering the block LATER leaves the dependencies unchanged but lets the current stream's own
+        next launches be issued -- under capture: created as graph nodes -- before the side work.  ROCm's graph executor
+        keeps a node's FIRST-created successor on the predecessor's hardware queue and moves later-created successors to
+        another queue, and an edge that changes queues costs ~10 us: the critical path must be captured first."""
         self.main = torch.cuda.current_stream(stream.device)
+        self.after = after
         # ``worthwhile`` = False: the caller knows the step is host-bound when run eagerly (small grids: the GPU waits
         # for Python, a fork only adds events and stream switches); under capture the fork always pays (a graph branch)
         self.forked = _INNER_FORKS and (worthwhile or torch.cuda.is_current_stream_capturing())
@@ -805,7 +815,10 @@ class _Fork:
 
     def __enter__(self):
         if self.forked:
-            self.stream.wait_stream(self.main)
+            if self.after is not None:
+                self.stream.wait_event(self.after)
+            else:
+                self.stream.wait_stream(self.main)
         self.ctx = torch.cuda.stream(self.stream)
         self.ctx.__enter__()
         return self
@@ -818,49 +831,48 @@ class _Fork:
             self.main.wait_stream(self.stream)
 
 
-class _TBPTTFn(torch.autograd.Function):
-    """All chunks of a truncated-BPTT forward pass (training.py:71-98) and their backward.
+def _tbptt_forward(states, actions, owner, surrogate, tau, tbtt, after_chunk=None):
+    """The forward launches of a TBPTT pass (see ``_TBPTTFn``).  ``after_chunk(c, st)`` -- if given -- is called right
+    after chunk ``c``'s rollout has been queued, with the pass's state so far (``st``: the namespace this function
+    returns): the pipelined training pass hangs that chunk's loss + backward branch there."""
+    b, t_total, _, n = actions.shape
+    cs, hq, ca = owner.chunk.c.cs, owner.chunk.c.hq, owner.chunk.c.ca
+    dev = actions.device
+    lib = load()
+    bounds = [(k0, min(k0 + tbtt, t_total)) for k0 in range(0, t_total, tbtt)]
+    nchunks = len(bounds)
+    (side,) = _side_streams(owner, dev, 1)
 
-    Forward: the state encoder of chunk 0 and the action encoder of ALL T steps run concurrently; then
-    chunk kernel, (1-state) encoder, chunk kernel, ...  Backward: TBPTT cuts the graph between chunks, so
-    the chunks' backward kernels are independent -- they run concurrently on side streams, each followed
-    by its state-encoder backward; the single action-encoder backward joins them.  Concurrent launches
-    get disjoint partial-gradient row ranges."""
+    actions_t = actions.transpose(0, 1).contiguous()                    # [T, B, 1, N]
+    states_t0 = states[:, :tau].transpose(0, 1).contiguous()            # [tau, B, 1, N]
+    lactions_t = torch.empty((t_total, b, ca, hq), device=dev, dtype=torch.float32)
+    # Action latents chunk by chunk on the side stream: chunk 0's first (the cell chain waits for them, beside the
+    # chunk-0 state encoding), the later chunks' while chunk 0's cell chain occupies only B of the 256 CUs.
+    asaved = _encoder_saved_buffer(owner.action_enc, t_total * b, dev)
+    af = 0 if asaved is None else asaved.shape[1]
+    nin, nlat = actions_t.shape[2] * n, ca * hq
+    lstates = [torch.empty((tau, b, cs, hq), device=dev, dtype=torch.float32)]
+    ssaved = [_encoder_saved_buffer(owner.state_enc, tau * b, dev)]
 
-    @staticmethod
-    def forward(ctx, states, actions, anchor, owner, surrogate, tau, tbtt):
-        b, t_total, _, n = actions.shape
-        cs, hq, ca = owner.chunk.c.cs, owner.chunk.c.hq, owner.chunk.c.ca
-        dev = actions.device
-        lib = load()
-        bounds = [(k0, min(k0 + tbtt, t_total)) for k0 in range(0, t_total, tbtt)]
-        nchunks = len(bounds)
-        (side,) = _side_streams(owner, dev, 1)
+    def action_job(k0, k1):
+        lo = k0 * b
+        return (owner.action_enc, actions_t.data_ptr() + 4 * lo * nin, (k1 - k0) * b, lactions_t.data_ptr() + 4 * lo * nlat,
+                None if asaved is None else asaved.data_ptr() + 4 * lo * af)
 
-        actions_t = actions.transpose(0, 1).contiguous()                    # [T, B, 1, N]
-        states_t0 = states[:, :tau].transpose(0, 1).contiguous()            # [tau, B, 1, N]
-        lactions_t = torch.empty((t_total, b, ca, hq), device=dev, dtype=torch.float32)
-        # Action latents chunk by chunk on the side stream: chunk 0's first (the cell chain waits for them, beside the
-        # chunk-0 state encoding), the later chunks' while chunk 0's cell chain occupies only B of the 256 CUs.
-        asaved = _encoder_saved_buffer(owner.action_enc, t_total * b, dev)
-        af = 0 if asaved is None else asaved.shape[1]
-        nin, nlat = actions_t.shape[2] * n, ca * hq
-        lstates = [torch.empty((tau, b, cs, hq), device=dev, dtype=torch.float32)]
-        ssaved = [_encoder_saved_buffer(owner.state_enc, tau * b, dev)]
+    split = asaved is not None and ssaved[0] is not None   # block-per-launch encoders need the saved records
+    if split:   # chunk-0 state encoding and chunk-0 action latents: one block-per-launch forward, both jobs per launch
+        _encoder_forward_multi(lib, [(owner.state_enc, states_t0.data_ptr(), tau * b, lstates[0].data_ptr(),
+                                      ssaved[0].data_ptr()), action_job(*bounds[0])])
+    # the other action latents on the side stream: with `split`, forked AFTER the launches above (which fill the
+    # device anyway) so that they run beside chunk 0's cell chain, which occupies only B of the 256 CUs
+    fork_point = None
+    if split and nchunks > 1 and _INNER_FORKS:
+        fork_point = torch.cuda.Event()
+        fork_point.record(torch.cuda.current_stream(dev))
+    fork = _Fork(side, worthwhile=n >= 128, after=fork_point)
+    lat_ready = {}
 
-        def action_job(k0, k1):
-            lo = k0 * b
-            return (owner.action_enc, actions_t.data_ptr() + 4 * lo * nin, (k1 - k0) * b, lactions_t.data_ptr() + 4 * lo * nlat,
-                    None if asaved is None else asaved.data_ptr() + 4 * lo * af)
-
-        split = asaved is not None and ssaved[0] is not None   # block-per-launch encoders need the saved records
-        if split:   # chunk-0 state encoding and chunk-0 action latents: one block-per-launch forward, both jobs per launch
-            _encoder_forward_multi(lib, [(owner.state_enc, states_t0.data_ptr(), tau * b, lstates[0].data_ptr(),
-                                          ssaved[0].data_ptr()), action_job(*bounds[0])])
-        # the other action latents on the side stream: with `split`, forked AFTER the launches above (which fill the
-        # device anyway) so that they run beside chunk 0's cell chain, which occupies only B of the 256 CUs
-        fork = _Fork(side, worthwhile=n >= 128)
-        lat_ready = {}
+    def encode_later_actions():
         with fork:
             for c, (k0, k1) in enumerate(bounds):
                 if split and c == 0:
@@ -879,49 +891,76 @@ class _TBPTTFn(torch.autograd.Function):
                 for t in (asaved, lactions_t, actions_t):
                     if t is not None:
                         t.record_stream(torch.cuda.current_stream(dev))
-        if not split:
-            _check(lib.sur_encoder_forward(_stream(), ctypes.byref(owner.state_enc.c), _p(states_t0), tau * b, _p(lstates[0]),
-                                           _p(ssaved[0])))
-        main = torch.cuda.current_stream(dev)
 
-        tm = surrogate.transition_model
-        h0, c0 = tm.H0.detach().contiguous(), tm.C0.detach().contiguous()   # one [cs, hq] state shared by the batch
-        s_lat = cs * hq
-        seeds, h0s, c0s, h_alls, c_alls, saveds = [states_t0], [h0], [c0], [], [], []
-        d_all = torch.empty((t_total, b, 1, n), device=dev, dtype=torch.float32)
-        out_all = torch.empty_like(d_all)
-        # one time-major tensor per quantity for ALL chunks: the backward pass then runs every chunk in the same launches
-        h_all_u = torch.empty((t_total, b, cs, hq), device=dev, dtype=torch.float32)
-        c_all_u = torch.empty_like(h_all_u)
-        saved_u = _saved_buffer(owner.chunk, t_total, b, dev)
-        for c, (k0, k1) in enumerate(bounds):
-            if c > 0:   # later chunks restart from the previous chunk's last prediction (gradients cut)
-                seeds.append(out_all[k0 - 1:k0])
-                lst = torch.empty((1, b, cs, hq), device=dev, dtype=torch.float32)
-                ssaved.append(_encoder_saved_buffer(owner.state_enc, b, dev))
-                _check(lib.sur_encoder_forward(_stream(), ctypes.byref(owner.state_enc.c), _p(seeds[c]), b, _p(lst),
-                                               _p(ssaved[c])))
-                lstates.append(lst)
-                h0s.append(h_alls[-1][-1])
-                c0s.append(c_alls[-1][-1])
-            k = k1 - k0
-            h_all, c_all, saved = h_all_u[k0:k1], c_all_u[k0:k1], saved_u[k0:k1]
-            s_used = min(seeds[c].shape[0], k)
-            if c in lat_ready:
-                main.wait_event(lat_ready[c])    # this chunk's action latents (encoded on the side stream)
-            _check(lib.sur_chunk_forward(_stream(), ctypes.byref(owner.chunk.c), _p(lactions_t[k0:k1]), _p(lstates[c]),
-                                         _p(seeds[c]), _p(h0s[c]), _p(c0s[c]), 0 if c == 0 else s_lat, k, s_used, b,
-                                         _p(h_all), _p(c_all), _p(d_all[k0:k1]), _p(out_all[k0:k1]), _p(saved)))
-            h_alls.append(h_all)
-            c_alls.append(c_all)
-            saveds.append(saved)
-        fork.join()
-        ctx.owner, ctx.bounds, ctx.dims = owner, bounds, (b, t_total, n, nchunks)
-        ctx.saved = (actions_t, lactions_t, seeds, lstates, h0s, c0s, h_alls, c_alls, saveds, asaved, ssaved)
-        ctx.unified = (h_all_u, c_all_u, saved_u)
+    if fork_point is None:
+        encode_later_actions()     # chunk 0's own action latents are among them (or nothing forks): before the chunk loop
+    if not split:
+        _check(lib.sur_encoder_forward(_stream(), ctypes.byref(owner.state_enc.c), _p(states_t0), tau * b, _p(lstates[0]),
+                                       _p(ssaved[0])))
+    main = torch.cuda.current_stream(dev)
+
+    tm = surrogate.transition_model
+    h0, c0 = tm.H0.detach().contiguous(), tm.C0.detach().contiguous()   # one [cs, hq] state shared by the batch
+    s_lat = cs * hq
+    seeds, h0s, c0s, h_alls, c_alls, saveds = [states_t0], [h0], [c0], [], [], []
+    d_all = torch.empty((t_total, b, 1, n), device=dev, dtype=torch.float32)
+    out_all = torch.empty_like(d_all)
+    # one time-major tensor per quantity for ALL chunks: the backward pass then runs every chunk in the same launches
+    h_all_u = torch.empty((t_total, b, cs, hq), device=dev, dtype=torch.float32)
+    c_all_u = torch.empty_like(h_all_u)
+    saved_u = _saved_buffer(owner.chunk, t_total, b, dev)
+    st = types.SimpleNamespace(b=b, t_total=t_total, n=n, nchunks=nchunks, bounds=bounds, s_lat=s_lat, actions_t=actions_t,
+                               lactions_t=lactions_t, seeds=seeds, lstates=lstates, h0s=h0s, c0s=c0s, h_alls=h_alls,
+                               c_alls=c_alls, saveds=saveds, asaved=asaved, ssaved=ssaved, d_all=d_all, out_all=out_all,
+                               h_all_u=h_all_u, c_all_u=c_all_u, saved_u=saved_u, split=split)
+    for c, (k0, k1) in enumerate(bounds):
+        if c > 0:   # later chunks restart from the previous chunk's last prediction (gradients cut)
+            seeds.append(out_all[k0 - 1:k0])
+            lst = torch.empty((1, b, cs, hq), device=dev, dtype=torch.float32)
+            ssaved.append(_encoder_saved_buffer(owner.state_enc, b, dev))
+            _check(lib.sur_encoder_forward(_stream(), ctypes.byref(owner.state_enc.c), _p(seeds[c]), b, _p(lst),
+                                           _p(ssaved[c])))
+            lstates.append(lst)
+            h0s.append(h_alls[-1][-1])
+            c0s.append(c_alls[-1][-1])
+        k = k1 - k0
+        h_all, c_all, saved = h_all_u[k0:k1], c_all_u[k0:k1], saved_u[k0:k1]
+        s_used = min(seeds[c].shape[0], k)
+        if c in lat_ready:
+            main.wait_event(lat_ready[c])    # this chunk's action latents (encoded on the side stream)
+        _check(lib.sur_chunk_forward(_stream(), ctypes.byref(owner.chunk.c), _p(lactions_t[k0:k1]), _p(lstates[c]),
+                                     _p(seeds[c]), _p(h0s[c]), _p(c0s[c]), 0 if c == 0 else s_lat, k, s_used, b,
+                                     _p(h_all), _p(c_all), _p(d_all[k0:k1]), _p(out_all[k0:k1]), _p(saved)))
+        h_alls.append(h_all)
+        c_alls.append(c_all)
+        saveds.append(saved)
+        if c == 0 and fork_point is not None:
+            encode_later_actions()  # forked at `fork_point`, issued after the critical path's own launches (see _Fork)
+        if after_chunk is not None:
+            after_chunk(c, st)
+    fork.join()
+    return st
+
+
+class _TBPTTFn(torch.autograd.Function):
+    """All chunks of a truncated-BPTT forward pass (training.py:71-98) and their backward.
+
+    Forward: the state encoder of chunk 0 and the action encoder of ALL T steps run concurrently; then
+    chunk kernel, (1-state) encoder, chunk kernel, ...  Backward: TBPTT cuts the graph between chunks, so
+    the chunks' backward kernels are independent -- they run concurrently on side streams, each followed
+    by its state-encoder backward; the single action-encoder backward joins them.  Concurrent launches
+    get disjoint partial-gradient row ranges."""
+
+    @staticmethod
+    def forward(ctx, states, actions, anchor, owner, surrogate, tau, tbtt):
+        st = _tbptt_forward(states, actions, owner, surrogate, tau, tbtt)
+        ctx.owner, ctx.bounds, ctx.dims = owner, st.bounds, (st.b, st.t_total, st.n, st.nchunks)
+        ctx.saved = (st.actions_t, st.lactions_t, st.seeds, st.lstates, st.h0s, st.c0s, st.h_alls, st.c_alls, st.saveds, st.asaved,
+                     st.ssaved)
+        ctx.unified = (st.h_all_u, st.c_all_u, st.saved_u)
         ctx.set_materialize_grads(False)
-        ctx.mark_non_differentiable(out_all)
-        return d_all, out_all, h_alls[-1][-1], c_alls[-1][-1]
+        ctx.mark_non_differentiable(st.out_all)
+        return st.d_all, st.out_all, st.h_alls[-1][-1], st.c_alls[-1][-1]
 
     @staticmethod
     def backward(ctx, dd_all, _dout, _dh, _dc):
@@ -994,3 +1033,105 @@ def fused_tbptt(surrogate, states, actions, tau, tbtt):
     owner = packs_for(surrogate, n, b)
     d_all, out_all, h, c = _TBPTTFn.apply(states, actions, owner.anchor, owner, surrogate, tau, tbtt)
     return out_all.transpose(0, 1), d_all.transpose(0, 1), (h, c), d_all
+
+
+PIPE_CHUNK_ROWS = 768   # partial rows (= workgroups of the pair-parallel backward kernels) of ONE chunk's backward branch
+
+
+def fused_tbptt_train(surrogate, states, actions, tau, tbtt, delta, mean, stdv):
+    """One whole TBPTT training pass WITHOUT autograd -- forward, delta loss, backward, gradient reduction (and the Adam
+    step, when the packs have been lent the optimizer descriptors) -- with the chunks **pipelined**: TBPTT cuts the graph
+    between chunks (training.py:71-98) and the delta loss is a plain sum over time steps (training.py:100-121), so the
+    loss rows + backward kernels + encoder backward of chunk c are queued on a branch stream as soon as chunk c has been
+    rolled out, and run while chunk c+1 is still going forward (its cell chains occupy B of the 256 CUs).  Only the last
+    chunk's backward is left on the critical path, at about half the (step, sample) pairs per launch.  Under hipGraph
+    capture the branches become parallel graph branches (each forked from the capturing stream itself: nested forks crash
+    hipStreamEndCapture on ROCm 7).
+
+    The gradient scale is fixed at d loss = 1: this is the captured training step (``GraphedTBPTTStep``); code that
+    calls ``loss.backward()`` itself goes through ``fused_tbptt`` + ``fused_delta_loss``.
+    Returns (outputs [B,T,1,N], outdeltas [B,T,1,N], (H, C), loss, hsteploss [T-1], stats [4], true deltas [B,T-1,1,N]),
+    or None when the pass cannot be pipelined (a single chunk, inner forks disabled, no saved-activation records)."""
+    b, t_total, _, n = actions.shape
+    if not _INNER_FORKS or t_total <= tbtt or t_total < 2:
+        return None
+    owner = packs_for(surrogate, n, b)
+    lib = load()
+    dev = actions.device
+    if not SAVE_ACTIVATIONS or min(lib.sur_encoder_saved_floats(ctypes.byref(owner.action_enc.c)),
+                                   lib.sur_encoder_saved_floats(ctypes.byref(owner.state_enc.c))) <= 0:
+        return None
+    bounds = [(k0, min(k0 + tbtt, t_total)) for k0 in range(0, t_total, tbtt)]
+    nchunks = len(bounds)
+    if states.stride(3) != 1:
+        states = states.contiguous()
+    # partial-gradient rows of every concurrent launch: disjoint, and reserved before the first launch (growing a buffer
+    # re-points the packs)
+    chunk_rows = [max(b, min((k1 - k0) * b, PIPE_CHUNK_ROWS)) for k0, k1 in bounds]
+    act_rows = [min(ENCODER_ROWS, (k1 - k0) * b) for k0, k1 in bounds]
+    st_rows = [min(ENCODER_ROWS, (tau if c == 0 else 1) * b) for c in range(nchunks)]
+    owner.chunk.ensure_rows(sum(chunk_rows))
+    owner.action_enc.ensure_rows(sum(act_rows))
+    owner.state_enc.ensure_rows(sum(st_rows))
+    owner.refresh_partials()
+    new = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)
+    deltas, hstep, loss, stats = new(b, t_total - 1, 1, n), new(t_total - 1), new(), new(4)
+    dd_all = new(t_total, b, 1, n)
+    scratch = owner.loss_scratch.get(t_total)
+    if scratch is None:
+        scratch = (torch.empty(40 * t_total, device=dev, dtype=torch.float64), torch.zeros(1, device=dev, dtype=torch.int32))
+        owner.loss_scratch[t_total] = scratch
+    partial, ticket = scratch
+    # ONE side stream carries everything that is off the critical path, in order: the action latents of the later chunks
+    # (_tbptt_forward), then the backward branch of chunk 0, of chunk 1, ...  A captured graph then has exactly two
+    # parallel node lists = two HIP streams; with three, two of them landed on the same hardware queue on some runs
+    # (ROCm maps streams onto GPU_MAX_HW_QUEUES = 4 queues) and the later chunks' latents queued behind a whole backward
+    # branch.  The backward kernels fill the device by themselves, so serialising the branches costs nothing.
+    (side,) = _side_streams(owner, dev, 1)
+    forks, keep = [], []
+
+    def backward_of(c, st):
+        k0, k1 = bounds[c]
+        k = k1 - k0
+        _check(lib.sur_tbptt_delta_loss_range(_stream(), _p(states), states.stride(0), states.stride(1), _p(st.d_all), b,
+                                              t_total, n, float(delta), float(mean), float(stdv), _p(deltas), _p(dd_all),
+                                              _p(hstep), _p(loss), _p(stats), _p(partial), _p(ticket), k0, k1))
+        dxlat = torch.empty_like(st.lactions_t[k0:k1])
+        dlst = torch.empty_like(st.lstates[c])
+        work = _chunk_workspace(owner.chunk, k, b, dev)
+        _check(lib.sur_chunk_backward(_stream(), ctypes.byref(owner.chunk.c), _p(st.lactions_t[k0:k1]), _p(st.lstates[c]),
+                                      _p(st.h0s[c]), _p(st.c0s[c]), 0 if c == 0 else st.s_lat, _p(st.h_alls[c]), _p(st.c_alls[c]),
+                                      _p(dd_all[k0:k1]), None, None, None, k, min(st.seeds[c].shape[0], k), b, _p(dxlat),
+                                      _p(dlst), None, None, sum(chunk_rows[:c]), chunk_rows[c], _p(st.saveds[c]), _p(work)))
+        _encoder_backward_multi(lib, [
+            (owner.action_enc, st.actions_t[k0:k1], dxlat, k * b, sum(act_rows[:c]), act_rows[c], st.asaved[k0 * b:k1 * b]),
+            (owner.state_enc, st.seeds[c], dlst, st.lstates[c].shape[0] * b, sum(st_rows[:c]), st_rows[c], st.ssaved[c])])
+        keep.extend((dxlat, dlst, work))
+
+    pending = []     # (chunk, fork point) whose backward branch has not been issued yet
+
+    def after_chunk(c, st):
+        # chunk c-1's branch forks where chunk c-1's rollout ended but is issued only now, after chunk c's own forward
+        # launches: the critical path's nodes must be created before a fork point's other successors (see _Fork)
+        for pc, point in pending:
+            fork = _Fork(side, after=point)
+            with fork:
+                backward_of(pc, st)
+            forks.append(fork)
+        del pending[:]
+        if c == nchunks - 1:
+            backward_of(c, st)            # the last chunk's backward IS the critical path: it stays on the main stream
+            return
+        point = torch.cuda.Event()
+        point.record(torch.cuda.current_stream(dev))
+        pending.append((c, point))
+
+    st = _tbptt_forward(states, actions, owner, surrogate, tau, tbtt, after_chunk=after_chunk)
+    for fork in forks:
+        fork.join()
+    for pack in owner.packs:
+        pack.dirty = True
+    owner.flush()
+    del keep[:]
+    return (st.out_all.transpose(0, 1), st.d_all.transpose(0, 1), (st.h_alls[-1][-1], st.c_alls[-1][-1]), loss, hstep, stats,
+            deltas)

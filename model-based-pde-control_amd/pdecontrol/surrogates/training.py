@@ -119,6 +119,37 @@ class PDETrainingModule(pl.LightningModule):
             return None
         return hipops.fused_delta_loss(self.surrogate, d_all, states, self.delta, *consts)
 
+    def _pipelined_training_step(self, batch):
+        """The whole training pass -- forward, loss, backward, gradient reduction (+ Adam when the captured step lent its
+        descriptors) -- in one hand-scheduled set of launches with the TBPTT chunks pipelined (``hipops.fused_tbptt_train``:
+        chunk c's backward runs beside chunk c+1's forward).  No autograd and d loss = 1, so this is for the captured step
+        only (``GraphedTBPTTStep``); returns None when the configuration is not the controller's (delta mode,
+        MSELoss(reduction="none"), affine undscaling, fused kernels) or the sequence is a single chunk."""
+        from pdecontrol.surrogates import ops
+        states, actions, *_ = batch
+        if not (ops.use_fused(states) and isinstance(self.surrogate, AutoRegPDESurrogate)) or self.training_mode != "delta":
+            return None
+        if not (isinstance(self.loss, torch.nn.MSELoss) and self.loss.reduction == "none"):
+            return None
+        from pdecontrol.surrogates import hipops
+        consts = hipops.undscale_constants(self.undscaling)
+        if consts is None or states.dtype != torch.float32 or states.shape[2] != 1:
+            return None
+        with torch.no_grad():
+            res = hipops.fused_tbptt_train(self.surrogate, states, actions, self.tau, self.tbtt, self.delta, *consts)
+        if res is None:
+            return None
+        outputs, outdeltas, _hidden, loss, hsteploss, stats, deltas = res
+        logged = {"Train Loss": loss, "Train Mean Delta Output": stats[0], "Train Std. Delta Output": stats[1],
+                  "Train Mean Delta": stats[2], "Train Std. Delta": stats[3]}
+        if torch.cuda.is_current_stream_capturing():
+            self.__dict__["_graph_logged"] = logged
+        else:
+            for name, value in logged.items():
+                self.log(name, value, on_step=False, on_epoch=True)
+        return {"loss": loss, "hsteploss": hsteploss, "outputs": outputs, "actions": actions.detach(),
+                "states": states.detach(), "outdeltas": outdeltas[:, :-1], "deltas": deltas}
+
     def training_step(self, batch, bidx):
         states = batch[0]
         if self.graphed and states.is_cuda:

@@ -80,6 +80,52 @@ def test_known_answer_b64_on_gpu(sur_golden, fused):
                                            err_msg=k)
 
 
+def test_pipelined_training_pass_against_reference_b64(sur_golden):
+    """The captured step's hand-scheduled pass (hipops.fused_tbptt_train: no autograd, chunk c's loss rows + backward on a
+    branch stream beside chunk c+1's forward) against the reference's known answer and gradients at the benchmarked batch."""
+    g = sur_golden
+    dev = torch.device("cuda", 0)
+    m = _module(dev)
+    gen = torch.Generator().manual_seed(1)
+    s = (torch.rand(64, 20, 1, 64, generator=gen) * 2 - 1).to(dev)
+    a = (torch.rand(64, 20, 1, 64, generator=gen) * 2 - 1).to(dev)
+    res = m._pipelined_training_step((s, a))
+    assert res is not None, "2 chunks of the controller's configuration must take the pipelined pass"
+    torch.cuda.synchronize(dev)
+    loss = res["loss"].item()
+    assert abs(loss - 10.806351661682129) / 10.806351661682129 < 1e-5
+    np.testing.assert_allclose(res["hsteploss"].cpu().numpy(), g["b64_hsteploss"], rtol=1e-4)
+    for k, p in m.surrogate.named_parameters():
+        if p.requires_grad:
+            ref = g["b64_grad/" + k]
+            np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=1e-2, atol=3e-5 * max(1.0, np.abs(ref).max()),
+                                       err_msg=k)
+
+
+@pytest.mark.parametrize("tbtt,T", [(10, 20), (7, 20), (6, 23)])
+def test_pipelined_pass_equals_autograd_pass(tbtt, T):
+    """2, 3 and 4 chunks (ragged last chunk): same loss / statistics / outputs / gradients as training_step + backward."""
+    from pdecontrol.surrogates import ops
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator().manual_seed(3)
+    s = (torch.rand(16, T, 1, 64, generator=gen) * 2 - 1).to(dev)
+    a = (torch.rand(16, T, 1, 64, generator=gen) * 2 - 1).to(dev)
+    ref_m, pipe_m = _module(dev, scaled=True), _module(dev, scaled=True)
+    ref_m.tbtt = pipe_m.tbtt = tbtt
+    with ops.fused(True):
+        ref = ref_m.training_step((s, a), 0)
+        ref["loss"].backward()
+        out = pipe_m._pipelined_training_step((s, a))
+    torch.cuda.synchronize(dev)
+    assert out is not None
+    for key in ("loss", "hsteploss", "outputs", "outdeltas", "deltas"):
+        np.testing.assert_allclose(out[key].cpu().numpy(), ref[key].detach().cpu().numpy(), rtol=1e-5, atol=1e-6, err_msg=key)
+    for (k, p), q in zip(ref_m.surrogate.named_parameters(), pipe_m.surrogate.parameters()):
+        if p.grad is not None:
+            scale = max(1.0, p.grad.abs().max().item())
+            np.testing.assert_allclose(q.grad.cpu().numpy(), p.grad.cpu().numpy(), rtol=1e-4, atol=2e-6 * scale, err_msg=k)
+
+
 @pytest.mark.parametrize("fused", [False, True])
 def test_hip_graph_step_equals_eager_training(fused):
     """Graph replay == eager training in pytorch-lightning's closure order (training_step -> zero_grad(set_to_none)
