@@ -190,6 +190,12 @@ int sur_tbptt_delta_loss(void* stream, const float* states, long states_bstride,
                          float stdv, float* deltas, float* dd_all, float* hsteploss, float* loss, float* stats,
                          double* partial, unsigned int* ticket);
 
+/* Fold partial-gradient rows [bases[j], bases[j] + counts[j]) of pack j (0: e0, 1: e1, 2: c2) into row dsts[j] of the same
+ * buffer (dst += sum, fixed order; dst outside the folded range) and re-zero them.  A backward branch that ends early
+ * (an early TBPTT chunk) folds its own rows, so the step's final sur_flush_all_grads reads one row per branch. */
+int sur_fold_rows(void* stream, const sur_encoder_params* e0, const sur_encoder_params* e1, const sur_chunk_params* c2,
+                  const int* bases, const int* counts, const int* dsts);
+
 /* The same loss over the time steps [t_begin, t_end) of the T rows only: the launches of one loss -- e.g. one per TBPTT
  * chunk, issued as soon as that chunk's predictions exist, on any streams and in any order -- must cover [0, T) exactly
  * once between them; `loss`, `hsteploss` and `stats` are written by whichever launch finishes last (the ticket counts

@@ -1446,6 +1446,93 @@ __device__ __forceinline__ void stage_range(const sur_chunk_params& p, int first
 }
 
 // (the chain kernels are instantiated per workgroup size: the 256-thread build keeps its register budget)
+// The whole forward chain of one sample with the state in registers (cs = 16, ca <= 4, hq = 16 * NSETS: exactly one
+// (channel, position) element per thread).  Per step and lane: 15 MFMAs whose A operands -- the gate weights -- were read
+// from global memory ONCE into 15 registers before the time loop, B operands gathered from the x / h buffers in LDS;
+// i, f, g, o, c', h' finished in the accumulator registers (same row <-> (channel, gate) map and the same summation order
+// as cell_forward_fused), c carried in a register, h' and the next step's x written to the OTHER of two LDS buffers and
+// every output stored to HBM straight from registers: ONE barrier per step, no LDS copy of h / c / gates, no weights in
+// LDS.  The next step's latent action and (teacher forcing) encoded state are fetched one step ahead.
+template <int NSETS>
+__device__ __forceinline__ void cell_chain_forward(const sur_chunk_params& p, float* lds, const float* __restrict__ xlat_t,
+                                                   const float* __restrict__ lstates_t, const float* __restrict__ h0,
+                                                   const float* __restrict__ c0, int hc_bstride, int K, int S, int B, int b,
+                                                   float* __restrict__ h_all, float* __restrict__ c_all,
+                                                   float* __restrict__ saved) {
+    const int hq = p.hq, ca = p.ca, s = 16 * hq, nx = ca * hq;
+    float* xb[2] = {lds, lds + nx};
+    float* hb[2] = {lds + 2 * nx, lds + 2 * nx + s};
+    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, tset = NSETS > 1 ? tid >> 8 : 0;
+    const int r = lane & 15, q = lane >> 4;
+    const int n = 16 * tset + r, ch = 4 * wave + q, idx = ch * hq + n;
+    // A operands: row r of this wave's tile = (gate r & 3, channel 4 * wave + (r >> 2)); lane (r, q) feeds k = q of each K block
+    const int gate_r = r & 3, ch_r = 4 * wave + (r >> 2);
+    const bool xq = q < ca;
+    float ax[3], ah[4][3];
+    {
+        const float* wx = p.w[SUR_ST_WXI + 3 * gate_r] + (ch_r * ca + (xq ? q : 0)) * 3;   // W_g[(o*cin + ci)*3 + tap]
+        const float* wh = p.w[SUR_ST_WHI + 3 * gate_r] + ch_r * 16 * 3;
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap) {
+            ax[tap] = xq ? wx[tap] : 0.0f;
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) ah[c4][tap] = wh[(4 * c4 + q) * 3 + tap];
+        }
+    }
+    const float bi = p.w[SUR_ST_BXI][ch], bf = p.w[SUR_ST_BXF][ch], bc = p.w[SUR_ST_BXC][ch], bo = p.w[SUR_ST_BXO][ch];
+    float c_reg = c0[(size_t)b * hc_bstride + idx];
+    hb[0][idx] = S > 0 ? lstates_t[(size_t)b * s + idx] : h0[(size_t)b * hc_bstride + idx];
+    if (tid < nx) xb[0][tid] = xlat_t[(size_t)b * nx + tid];
+    const size_t save_stride = step_saved_floats(p);
+    int colx[3];
+#pragma unroll
+    for (int tap = 0; tap < 3; ++tap) colx[tap] = wrapi(n + tap - 1, hq);
+    __syncthreads();
+    for (int k = 0; k < K; ++k) {
+        const size_t kb = (size_t)k * B + b;
+        const bool nxt = k + 1 < K, next_forced = nxt && k + 1 < S;
+        float xnext = 0.0f, hforced = 0.0f;
+        if (nxt && tid < nx) xnext = xlat_t[(kb + B) * nx + tid];
+        if (next_forced) hforced = lstates_t[(kb + B) * s + idx];
+        const float* xc = xb[k & 1];
+        const float* hc = hb[k & 1];
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap) {
+            const int col = colx[tap];
+            const float bx = xc[(xq ? q : 0) * hq + col];
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[tap], xq ? bx : 0.f, acc0, 0, 0, 0);
+#pragma unroll
+            for (int c0_ = 0; c0_ < 4; c0_ += 2) {
+                const float b0 = hc[(4 * c0_ + q) * hq + col], b1 = hc[(4 * c0_ + 4 + q) * hq + col];
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[c0_][tap], b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[c0_ + 1][tap], b1, acc1, 0, 0, 0);
+            }
+        }
+        const float gi = sigmoid_(acc0[0] + acc1[0] + bi), gf = sigmoid_(acc0[1] + acc1[1] + bf),
+                    gg = tanhf(acc0[2] + acc1[2] + bc), go = sigmoid_(acc0[3] + acc1[3] + bo);
+        const float cn = fmaf(gf, c_reg, gi * gg);
+        const float hn = go * tanhf(cn);
+        c_reg = cn;
+        h_all[kb * s + idx] = hn;
+        c_all[kb * s + idx] = cn;
+        if (saved) {   // [gates | c_k | h_k]
+            float* dst = saved + kb * save_stride + idx;
+            dst[0] = gi;
+            dst[s] = gf;
+            dst[2 * s] = gg;
+            dst[3 * s] = go;
+            dst[4 * s] = cn;
+            dst[5 * s] = hn;
+        }
+        if (nxt) {
+            hb[(k + 1) & 1][idx] = next_forced ? hforced : hn;   // teacher forcing replaces H
+            if (tid < nx) xb[(k + 1) & 1][tid] = xnext;
+        }
+        __syncthreads();
+    }
+}
+
 template <int MAXT>
 __global__ void __launch_bounds__(MAXT)
 cell_fwd_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, const float* __restrict__ lstates_t,
@@ -1453,6 +1540,14 @@ cell_fwd_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, cons
                 float* __restrict__ h_all, float* __restrict__ c_all, float* __restrict__ saved) {
     extern __shared__ __align__(16) float lds[];
     const int b = blockIdx.x, s = p.cs * p.hq, nx = p.ca * p.hq;
+#ifndef SUR_STAMP
+    if constexpr ((MAXT & 255) == 0) {
+        if (p.cs == 16 && p.ca <= 4 && p.hq * 16 == MAXT) {   // one (channel, position) element per thread
+            cell_chain_forward<MAXT / 256>(p, lds, xlat_t, lstates_t, h0, c0, hc_bstride, K, S, B, b, h_all, c_all, saved);
+            return;
+        }
+    }
+#endif
     StepLayout L{};
     L.x = lds;
     L.h = L.x + nx;
@@ -1467,6 +1562,7 @@ cell_fwd_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, cons
         L.hnew[i] = h0[(size_t)b * hc_bstride + i];   // hc_bstride = 0: one initial state shared by the batch
         L.cnew[i] = c0[(size_t)b * hc_bstride + i];
     }
+    STAMP(109);
     // the next step's latent action is fetched while this step computes
     float xn[4];
 #pragma unroll
@@ -1484,12 +1580,14 @@ cell_fwd_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, cons
             L.c[i] = L.cnew[i];
         }
         __syncthreads();
+        STAMP(k < S ? 110 : 111);
         if (k + 1 < K) {
 #pragma unroll
             for (int u = 0; u < 4; ++u)
                 if (threadIdx.x + u * MAXT < nx) xn[u] = xlat_t[(kb + B) * nx + threadIdx.x + u * MAXT];
         }
         cell_forward<MAXT>(p, L, w);
+        STAMP(112);
         for (int i = threadIdx.x; i < s; i += blockDim.x) {
             h_all[kb * s + i] = L.hnew[i];
             c_all[kb * s + i] = L.cnew[i];
@@ -1500,6 +1598,7 @@ cell_fwd_kernel(const sur_chunk_params p, const float* __restrict__ xlat_t, cons
             for (int i = threadIdx.x; i < (6 * s) >> 2; i += blockDim.x) dst[i] = src[i];
         }
         __syncthreads();
+        STAMP(113);
     }
 }
 
@@ -1784,7 +1883,10 @@ cell_wgrad_kernel(const sur_chunk_params p, const ChunkSpans spans, const float*
 // consumed on the spot: g = sum (not accumulated), then the torch.optim.Adam update of the parameter element
 // (no weight decay, no amsgrad; same formula as torch's fused kernel) -- the optimizer costs no extra launch and the
 // gradients need no zeroing pass.
-constexpr int FLUSH_COLS = 32, FLUSH_RG = TPB / FLUSH_COLS;   // 16 columns (twice the blocks) measured slower: 34 vs 26 us
+#ifndef FLUSH_TPB
+#define FLUSH_TPB 1024   // the reduction over rows is a latency chain (rows / FLUSH_RG / 8 rounds of loads): 1024 threads = 32 row groups
+#endif
+constexpr int FLUSH_COLS = 32, FLUSH_RG = FLUSH_TPB / FLUSH_COLS;   // 16 columns (twice the blocks) measured slower: 34 vs 26 us
 __host__ __device__ inline int flush_blocks(int psize) { return (psize + FLUSH_COLS - 1) / FLUSH_COLS; }
 
 template <int NP, typename Params>
@@ -1856,12 +1958,12 @@ __device__ __forceinline__ void flush_grads_body(const Params& p, int psize, con
 }
 
 template <int NP, typename Params>
-__global__ void __launch_bounds__(TPB) flush_grads_kernel(const Params p, int psize, const sur_adam adam, int overwrite) {
+__global__ void __launch_bounds__(FLUSH_TPB) flush_grads_kernel(const Params p, int psize, const sur_adam adam, int overwrite) {
     flush_grads_body<NP, Params>(p, psize, adam, overwrite != 0, blockIdx.x, gridDim.x);
 }
 
 // the three gradient reductions of a surrogate (state encoder, action encoder, chunk) in one launch
-__global__ void __launch_bounds__(TPB)
+__global__ void __launch_bounds__(FLUSH_TPB)
 flush_all_kernel(const sur_encoder_params e0, const sur_adam a0, int n0, const sur_encoder_params e1, const sur_adam a1, int n1,
                  const sur_chunk_params c2, const sur_adam a2, int n2, int overwrite_mask) {
     const int b0 = flush_blocks(n0), b1 = flush_blocks(n1), b2 = flush_blocks(n2);
@@ -1869,6 +1971,57 @@ flush_all_kernel(const sur_encoder_params e0, const sur_adam a0, int n0, const s
     if (blk < b0) flush_grads_body<SUR_ENC_NPARAM, sur_encoder_params>(e0, n0, a0, overwrite_mask & 1, blk, b0);
     else if (blk < b0 + b1) flush_grads_body<SUR_ENC_NPARAM, sur_encoder_params>(e1, n1, a1, overwrite_mask & 2, blk - b0, b1);
     else flush_grads_body<SUR_ST_NPARAM, sur_chunk_params>(c2, n2, a2, overwrite_mask & 4, blk - b0 - b1, b2);
+}
+
+// Fold the partial-gradient rows [base, base + count) of up to three packs into ONE row each (dst += their sum, fixed order)
+// and re-zero them: what a backward branch that finishes early does with its own rows, so that the reduction at the end
+// of the step (flush) reads one row per branch instead of hundreds (hipops.fused_tbptt_train).
+struct FoldJob {
+    float* partial;
+    int psize, base, count, dst;
+};
+
+__device__ __forceinline__ void fold_rows_body(const FoldJob& j, int blk) {
+    __shared__ float part[FLUSH_RG][FLUSH_COLS + 1];
+    const int col = threadIdx.x & (FLUSH_COLS - 1), rg = threadIdx.x / FLUSH_COLS;
+    const int t = blk * FLUSH_COLS + col;
+    float acc = 0.0f;
+    if (t < j.psize) {
+        constexpr int U = 8;
+        float* src = j.partial + (size_t)j.base * j.psize + t;
+        for (int r0 = rg; r0 < j.count; r0 += FLUSH_RG * U) {
+            float v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int r = r0 + FLUSH_RG * u;
+                v[u] = r < j.count ? src[(size_t)r * j.psize] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int r = r0 + FLUSH_RG * u;
+                if (r < j.count) {
+                    acc += v[u];
+                    src[(size_t)r * j.psize] = 0.0f;
+                }
+            }
+        }
+    }
+    part[rg][col] = acc;
+    __syncthreads();
+    if (rg == 0 && t < j.psize) {
+        float tot = 0.0f;
+#pragma unroll
+        for (int i = 0; i < FLUSH_RG; ++i) tot += part[i][col];
+        j.partial[(size_t)j.dst * j.psize + t] += tot;
+    }
+}
+
+__global__ void __launch_bounds__(FLUSH_TPB) fold_rows_kernel(const FoldJob j0, const FoldJob j1, const FoldJob j2) {
+    const int b0 = flush_blocks(j0.psize), b1 = flush_blocks(j1.psize);
+    const int blk = blockIdx.x;
+    if (blk < b0) fold_rows_body(j0, blk);
+    else if (blk < b0 + b1) fold_rows_body(j1, blk - b0);
+    else fold_rows_body(j2, blk - b0 - b1);
 }
 
 // torch.optim.Adam (no weight decay / amsgrad) of a whole parameter pack from its gradient tensors: the optimizer of the
@@ -2098,7 +2251,7 @@ int sur_flush_encoder_grads(void* stream, const sur_encoder_params* p, const sur
         ad = *adam;
     }
     return launch_checked([&] {
-        hipLaunchKernelGGL((flush_grads_kernel<SUR_ENC_NPARAM, sur_encoder_params>), dim3(flush_blocks(psize)), dim3(TPB), 0,
+        hipLaunchKernelGGL((flush_grads_kernel<SUR_ENC_NPARAM, sur_encoder_params>), dim3(flush_blocks(psize)), dim3(FLUSH_TPB), 0,
                            (hipStream_t)stream, *p, psize, ad, overwrite);
     }, "flush_enc");
 }
@@ -2264,7 +2417,7 @@ int sur_flush_chunk_grads(void* stream, const sur_chunk_params* p, const sur_ada
         ad = *adam;
     }
     return launch_checked([&] {
-        hipLaunchKernelGGL((flush_grads_kernel<SUR_ST_NPARAM, sur_chunk_params>), dim3(flush_blocks(psize)), dim3(TPB), 0,
+        hipLaunchKernelGGL((flush_grads_kernel<SUR_ST_NPARAM, sur_chunk_params>), dim3(flush_blocks(psize)), dim3(FLUSH_TPB), 0,
                            (hipStream_t)stream, *p, psize, ad, overwrite);
     }, "flush_chunk");
 }
@@ -2287,9 +2440,30 @@ int sur_flush_all_grads(void* stream, const sur_encoder_params* e0, const sur_ad
     const int n0 = psize_of<SUR_ENC_NPARAM>(e0->size), n1 = psize_of<SUR_ENC_NPARAM>(e1->size), n2 = psize_of<SUR_ST_NPARAM>(c2->size);
     const int grid = flush_blocks(n0) + flush_blocks(n1) + flush_blocks(n2);
     return launch_checked([&] {
-        hipLaunchKernelGGL(flush_all_kernel, dim3(grid), dim3(TPB), 0, (hipStream_t)stream, *e0, ad[0], n0, *e1, ad[1], n1, *c2, ad[2],
+        hipLaunchKernelGGL(flush_all_kernel, dim3(grid), dim3(FLUSH_TPB), 0, (hipStream_t)stream, *e0, ad[0], n0, *e1, ad[1], n1, *c2, ad[2],
                            n2, overwrite_mask);
     }, "flush_all");
+}
+
+int sur_fold_rows(void* stream, const sur_encoder_params* e0, const sur_encoder_params* e1, const sur_chunk_params* c2,
+                  const int* bases, const int* counts, const int* dsts) {
+    if (!e0 || !e1 || !c2 || !bases || !counts || !dsts) return fail(-1, "sur_fold_rows: bad argument");
+    float* partial[3] = {e0->partial, e1->partial, c2->partial};
+    const int rows[3] = {e0->rows, e1->rows, c2->rows};
+    const int psize[3] = {psize_of<SUR_ENC_NPARAM>(e0->size), psize_of<SUR_ENC_NPARAM>(e1->size), psize_of<SUR_ST_NPARAM>(c2->size)};
+    FoldJob jobs[3];
+    int grid = 0;
+    for (int j = 0; j < 3; ++j) {
+        if (!partial[j] || bases[j] < 0 || counts[j] <= 0 || bases[j] + counts[j] > rows[j] || dsts[j] < 0 || dsts[j] >= rows[j] ||
+            (dsts[j] >= bases[j] && dsts[j] < bases[j] + counts[j]))
+            return fail(-1, "sur_fold_rows: pack %d: rows [%d, %d) -> row %d do not fit the buffer of %d rows", j, bases[j],
+                        bases[j] + counts[j], dsts[j], rows[j]);
+        jobs[j] = FoldJob{partial[j], psize[j], bases[j], counts[j], dsts[j]};
+        grid += flush_blocks(psize[j]);
+    }
+    return launch_checked([&] {
+        hipLaunchKernelGGL(fold_rows_kernel, dim3(grid), dim3(FLUSH_TPB), 0, (hipStream_t)stream, jobs[0], jobs[1], jobs[2]);
+    }, "fold_rows");
 }
 
 int sur_adam_apply(void* stream, const sur_encoder_params* e0, const sur_adam* a0, const sur_encoder_params* e1,

@@ -75,6 +75,7 @@ SYMBOLS = (
     ("sur_adam_apply", [_fp, _EP, _AP, _EP, _AP, _CP, _AP]),
     ("sur_tbptt_delta_loss", [_fp, _fp, ctypes.c_long, ctypes.c_long, _fp, _i, _i, _i, ctypes.c_float, ctypes.c_float, ctypes.c_float, _fp, _fp, _fp, _fp,
                               _fp, _fp, _fp]),
+    ("sur_fold_rows", [_fp, _EP, _EP, _CP, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     ("sur_tbptt_delta_loss_range", [_fp, _fp, ctypes.c_long, ctypes.c_long, _fp, _i, _i, _i, ctypes.c_float, ctypes.c_float,
                                     ctypes.c_float, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i]),
 )
@@ -1070,9 +1071,20 @@ def fused_tbptt_train(surrogate, states, actions, tau, tbtt, delta, mean, stdv):
     chunk_rows = [max(b, min((k1 - k0) * b, PIPE_CHUNK_ROWS)) for k0, k1 in bounds]
     act_rows = [min(ENCODER_ROWS, (k1 - k0) * b) for k0, k1 in bounds]
     st_rows = [min(ENCODER_ROWS, (tau if c == 0 else 1) * b) for c in range(nchunks)]
-    owner.chunk.ensure_rows(sum(chunk_rows))
-    owner.action_enc.ensure_rows(sum(act_rows))
-    owner.state_enc.ensure_rows(sum(st_rows))
+    # row layout per pack: [ last chunk's rows | ONE fold row | chunk 0's rows | chunk 1's rows | ... ].  Each side branch
+    # folds its own rows into the fold row when it is done (sur_fold_rows), so the flush at the end of the step reads the
+    # last chunk's rows + 1 instead of every chunk's.
+    def layout(rows):
+        base, nxt = [0] * nchunks, rows[-1] + 1
+        for c in range(nchunks - 1):
+            base[c], nxt = nxt, nxt + rows[c]
+        return base, rows[-1], nxt          # per-chunk row base, fold row, rows in total
+    chunk_base, chunk_fold, chunk_total = layout(chunk_rows)
+    act_base, act_fold, act_total = layout(act_rows)
+    st_base, st_fold, st_total = layout(st_rows)
+    owner.chunk.ensure_rows(chunk_total)
+    owner.action_enc.ensure_rows(act_total)
+    owner.state_enc.ensure_rows(st_total)
     owner.refresh_partials()
     new = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)
     deltas, hstep, loss, stats = new(b, t_total - 1, 1, n), new(t_total - 1), new(), new(4)
@@ -1102,10 +1114,15 @@ def fused_tbptt_train(surrogate, states, actions, tau, tbtt, delta, mean, stdv):
         _check(lib.sur_chunk_backward(_stream(), ctypes.byref(owner.chunk.c), _p(st.lactions_t[k0:k1]), _p(st.lstates[c]),
                                       _p(st.h0s[c]), _p(st.c0s[c]), 0 if c == 0 else st.s_lat, _p(st.h_alls[c]), _p(st.c_alls[c]),
                                       _p(dd_all[k0:k1]), None, None, None, k, min(st.seeds[c].shape[0], k), b, _p(dxlat),
-                                      _p(dlst), None, None, sum(chunk_rows[:c]), chunk_rows[c], _p(st.saveds[c]), _p(work)))
+                                      _p(dlst), None, None, chunk_base[c], chunk_rows[c], _p(st.saveds[c]), _p(work)))
         _encoder_backward_multi(lib, [
-            (owner.action_enc, st.actions_t[k0:k1], dxlat, k * b, sum(act_rows[:c]), act_rows[c], st.asaved[k0 * b:k1 * b]),
-            (owner.state_enc, st.seeds[c], dlst, st.lstates[c].shape[0] * b, sum(st_rows[:c]), st_rows[c], st.ssaved[c])])
+            (owner.action_enc, st.actions_t[k0:k1], dxlat, k * b, act_base[c], act_rows[c], st.asaved[k0 * b:k1 * b]),
+            (owner.state_enc, st.seeds[c], dlst, st.lstates[c].shape[0] * b, st_base[c], st_rows[c], st.ssaved[c])])
+        if c < nchunks - 1:
+            three = ctypes.c_int * 3
+            _check(lib.sur_fold_rows(_stream(), ctypes.byref(owner.state_enc.c), ctypes.byref(owner.action_enc.c),
+                                     ctypes.byref(owner.chunk.c), three(st_base[c], act_base[c], chunk_base[c]),
+                                     three(st_rows[c], act_rows[c], chunk_rows[c]), three(st_fold, act_fold, chunk_fold)))
         keep.extend((dxlat, dlst, work))
 
     pending = []     # (chunk, fork point) whose backward branch has not been issued yet
@@ -1129,9 +1146,13 @@ def fused_tbptt_train(surrogate, states, actions, tau, tbtt, delta, mean, stdv):
     st = _tbptt_forward(states, actions, owner, surrogate, tau, tbtt, after_chunk=after_chunk)
     for fork in forks:
         fork.join()
-    for pack in owner.packs:
+    for pack, extent in ((owner.state_enc, st_fold + 1), (owner.action_enc, act_fold + 1), (owner.chunk, chunk_fold + 1)):
         pack.dirty = True
-    owner.flush()
+        pack.c.rows = extent            # what the flush reduces and re-zeroes: everything beyond has been folded (and zeroed)
+    try:
+        owner.flush()
+    finally:
+        owner.refresh_partials()
     del keep[:]
     return (st.out_all.transpose(0, 1), st.d_all.transpose(0, 1), (st.h_alls[-1][-1], st.c_alls[-1][-1]), loss, hstep, stats,
             deltas)

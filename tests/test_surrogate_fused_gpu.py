@@ -186,7 +186,9 @@ def test_ensemble_parallel_step_equals_member_by_member(dev):
         ops.enable_fused(True)
         seq_losses, seq_params = [], []
         for i in range(3):
-            g = GraphedTBPTTStep(build_module(dev, seed=i), tuple(batches[i][0].shape))
+            # pipelined=False: the launch structure of an ensemble member (a member runs on a forked stream of the
+            # ensemble capture and cannot fork again, so it keeps every chunk's backward in the same launches)
+            g = GraphedTBPTTStep(build_module(dev, seed=i), tuple(batches[i][0].shape), pipelined=False)
             g.step(*batches[i])
             seq_losses.append([float(g.step()["loss"].detach()) for _ in range(3)])
             seq_params.append(torch.cat([p.detach().reshape(-1) for p in g.module.surrogate.parameters()]).clone())
@@ -381,6 +383,8 @@ def test_pack_adam_matches_torch_adam_and_lightning_closure_order(dev):
     torch.cuda.synchronize(dev)
     assert m.surrogate._fused_packs.adam_step_count() == 5
     for (name, p), q in zip(m.surrogate.named_parameters(), ref.surrogate.parameters()):
-        np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), rtol=2e-5, atol=2e-7, err_msg=name)
+        # atol: Adam's update lr * m / sqrt(v) turns a 1-ulp difference of a near-zero gradient into O(1e-4) of a step
+        # (lr = 1e-3, five steps: parameters move by up to 5e-3)
+        np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), rtol=2e-5, atol=1e-6, err_msg=name)
     sd = opt.state_dict()
     assert sd["packs"][2]["step"] == 5 and sd["param_groups"][0]["lr"] == 2.5e-4
