@@ -1728,6 +1728,118 @@ struct ChunkSpans {
     sur_chunk_span sp[SUR_MAX_SPANS];
     int n;
 };
+// The backward chain of one (chunk, sample) for cs = 16, hq = 16 * NSETS (one (channel, position) element per thread), built
+// like cell_chain_forward: the recurrent weights Wh_g^T are read from global memory ONCE into 12 registers per lane (wave
+// group g = wave / NSETS contracts gate g, K = 48, for the column tile wave % NSETS), LDS holds only the gate derivatives
+// and the four partial dh tiles, and everything a step reads from HBM -- its activated gates and c_k (saved by the forward),
+// c_{k-1}, the decoder's dh -- is fetched TWO steps ahead into registers, so no step waits for memory (with one step of
+// lead, LDS-DMA + prefetch, the loads landed ~1 us after they were needed).  Two barriers per step remain: the gate
+// derivatives of all channels feed every wave's GEMM, and the four gates' partial tiles are summed by the next step.
+struct CellBwdIn {
+    float g[5], cp, dhd;   // activated gates i f g o, c_k; c_{k-1}; d loss / d h_k from the decoder
+};
+
+template <int NSETS>
+__device__ __forceinline__ void cell_chain_backward(const sur_chunk_params& p, float* lds, const sur_chunk_span& sp, int b, int B,
+                                                    const float* __restrict__ c_all, const float* __restrict__ saved,
+                                                    const float* __restrict__ dh_dec, const float* __restrict__ dh_all,
+                                                    const float* __restrict__ dc_all, float* __restrict__ dg_all,
+                                                    float* __restrict__ dh0, float* __restrict__ dc0) {
+    const int hq = p.hq, s = 16 * hq;
+    const int K0 = sp.k0, K = sp.k1, S = sp.k0 + sp.s;
+    const float* __restrict__ c0 = sp.c0;
+    const int hc_bstride = sp.hc_bstride;
+    float* __restrict__ dlstates_t = sp.dlstates_t;
+    float* dgates = lds;              // [4][s]
+    float* part = lds + 4 * s;        // [4][s]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int gt = wid / NSETS, n0 = 16 * (wid % NSETS);
+    const size_t save_stride = step_saved_floats(p);
+    // A[m = ci][k = o][tap] = Wh_g[(o * 16 + ci) * 3 + tap]; lane (r, q): row ci = r, k = q of each block of four o
+    float a[3][4];
+    {
+        const float* wh = p.w[SUR_ST_WHI + 3 * gt];
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap)
+#pragma unroll
+            for (int blk = 0; blk < 4; ++blk) a[tap][blk] = wh[((4 * blk + q) * 16 + r) * 3 + tap];
+    }
+    int colj[3];
+#pragma unroll
+    for (int tap = 0; tap < 3; ++tap) colj[tap] = wrapi(n0 + r - tap + 1, hq);
+    const int i = tid;   // this thread's element of [cs][hq]
+    auto fetch = [&](int kk, CellBwdIn& in) {
+        const float* rec = saved + ((size_t)kk * B + b) * save_stride + i;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) in.g[j] = rec[(size_t)j * s];
+        in.cp = kk > K0 ? c_all[((size_t)(kk - 1) * B + b) * s + i] : c0[(size_t)b * hc_bstride + i];
+        in.dhd = dh_dec[((size_t)kk * B + b) * s + i];
+    };
+    CellBwdIn cur{}, nx1{}, nx2{};
+    fetch(K - 1, cur);
+    if (K - 2 >= K0) fetch(K - 2, nx1);
+    float dcc = 0.0f;
+    for (int k = K - 1; k >= K0 - 1; --k) {
+        if (k - 2 >= K0) fetch(k - 2, nx2);
+        // ---- A: what step k+1's GEMM produced, then (k >= K0) this step's gate derivative ----
+        const bool have_prev = k + 1 < K, prev_forced = have_prev && k + 1 < S;
+        float dh_in = 0.0f;
+        if (have_prev) {
+            const float v_ = (part[i] + part[s + i]) + (part[2 * s + i] + part[3 * s + i]);
+            if (prev_forced) {
+                if (dlstates_t) dlstates_t[((size_t)(k + 1 - K0) * B + b) * s + i] = v_;
+            } else {
+                dh_in = v_;
+            }
+        }
+        if (k < K0) {   // past the first step: what is left goes to the initial state
+            if (dh0) dh0[(size_t)b * s + i] = dh_in;
+            if (dc0) dc0[(size_t)b * s + i] = dcc;
+            break;
+        }
+        const size_t kb = (size_t)k * B + b;
+        const float dhn = cur.dhd + dh_in + (dh_all ? dh_all[kb * s + i] : 0.0f);
+        const float gi = cur.g[0], gf = cur.g[1], gg = cur.g[2], go = cur.g[3];
+        const float tc = tanhf(cur.g[4]);
+        const float dcn = dcc + (dc_all ? dc_all[kb * s + i] : 0.0f) + dhn * go * (1.0f - tc * tc);
+        const float d0 = dcn * gg * gi * (1.0f - gi), d1 = dcn * cur.cp * gf * (1.0f - gf),
+                    d2 = dcn * gi * (1.0f - gg * gg), d3 = dhn * tc * go * (1.0f - go);
+        dgates[i] = d0;
+        dgates[s + i] = d1;
+        dgates[2 * s + i] = d2;
+        dgates[3 * s + i] = d3;
+        float* dg = dg_all + kb * 4 * s;
+        dg[i] = d0;
+        dg[s + i] = d1;
+        dg[2 * s + i] = d2;
+        dg[3 * s + i] = d3;
+        dcc = dcn * gf;   // gradient wrt c_{k-1}
+        __syncthreads();
+        // ---- B: dh_{k-1} partial of gate gt, column tile n0: sum_{o, tap} Wh_gt[o][ci][tap] * dG_gt[o][j - tap + 1] ----
+        {
+            const float* bsrc = dgates + gt * s;
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int tap = 0; tap < 3; ++tap) {
+                const float* bp = bsrc + colj[tap];
+#pragma unroll
+                for (int blk = 0; blk < 4; blk += 2) {
+                    const float b0 = bp[(4 * blk + q) * hq], b1 = bp[(4 * blk + 4 + q) * hq];
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tap][blk], b0, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tap][blk + 1], b1, acc1, 0, 0, 0);
+                }
+            }
+            float* dst = part + gt * s + n0 + r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dst[(4 * q + e) * hq] = acc0[e] + acc1[e];
+        }
+        cur = nx1;
+        nx1 = nx2;
+        __syncthreads();
+    }
+}
+
 template <int MAXT>
 __global__ void __launch_bounds__(MAXT)
 cell_bwd_kernel(const sur_chunk_params p, const ChunkSpans spans, const float* __restrict__ c_all,
@@ -1738,6 +1850,14 @@ cell_bwd_kernel(const sur_chunk_params p, const ChunkSpans spans, const float* _
     // workgroup -> (chunk of the time axis, sample): the chunks' chains are independent (TBPTT cuts the graph)
     const sur_chunk_span sp = spans.sp[blockIdx.x / B];
     const int b = blockIdx.x % B, s = p.cs * p.hq;
+#ifndef SUR_STAMP
+    if constexpr ((MAXT & 255) == 0) {
+        if (p.cs == 16 && p.hq * 16 == MAXT) {   // one (channel, position) element per thread
+            cell_chain_backward<MAXT / 256>(p, lds, sp, b, B, c_all, saved, dh_dec, dh_all, dc_all, dg_all, dh0, dc0);
+            return;
+        }
+    }
+#endif
     const int K0 = sp.k0, K = sp.k1, S = sp.k0 + sp.s;   // steps K0 .. K-1 (global time index), the first sp.s teacher forced
     const float* __restrict__ c0 = sp.c0;
     const int hc_bstride = sp.hc_bstride;
@@ -1819,12 +1939,15 @@ cell_bwd_kernel(const sur_chunk_params p, const ChunkSpans spans, const float* _
         }
         if (k < K0) break;
         __syncthreads();
+        STAMP(120);
         // ---- B: prefetches for step k-1, then dh_{k-1} partials ----
         if (k > K0) {
             fetch_block(k - 1);
             prefetch(k - 1);
         }
+        STAMP(121);
         cell_dh_gemm(p, L, w, part);   // ends with the barrier that also retires the DMA
+        STAMP(122);
     }
 }
 

@@ -187,7 +187,10 @@ def run_size(device, N, steps, warmup, B=64, with_plain=True, with_ensemble=True
     ms = res["hip_graph_fused"]["ms_per_step"]
     bytes_model = _hbm_model_bytes(B, 20, N)
     res["value"] = res["hip_graph_fused"]["value"]
-    res["roofline"] = {"bound": "latency (dependent layer phases, one workgroup per sequence)", "kernels_per_step": 21,
+    res["hip_graph_fused"]["schedule"] = ("chunks pipelined: chunk 0's loss rows + backward on a side branch beside chunk 1's "
+                                          "forward (hipops.fused_tbptt_train); PDECONTROL_PIPELINED=0 for every chunk's backward "
+                                          "in the same launches")
+    res["roofline"] = {"bound": "latency (dependent layer phases, one workgroup per sequence)", "kernels_per_step": 29,
                        "reference_torch_ops_per_step": "~4 000", "hbm_model_bytes_per_step": bytes_model,
                        "hbm_model_gbs": bytes_model / (ms * 1e-3) / 1e9, "hbm_frac_of_8TBs": bytes_model / (ms * 1e-3) / 8e12}
     # parity of the measured configuration: first-step loss GPU (fused) vs CPU (contract: 1e-5 relative)

@@ -29,5 +29,7 @@ for rep in range(3):
 print(f"N = {N}: cell_fwd_kernel workgroup 0, both chunks (20 steps: 6 teacher forced), cycles summed")
 for i, name in ((109, "prologue (weights, h0/c0)"), (110, "step head, teacher forced (x, h <- lstates (global), c)"),
                 (111, "step head, free running (x, h, c from LDS)"), (112, "cell_forward (gates GEMM + activations)"),
-                (113, "stores h_all / c_all / saved + barrier")):
+                (113, "stores h_all / c_all / saved + barrier"),
+                (120, "cell_bwd A: partial sums + gate derivative + dg_all store"), (121, "cell_bwd: issue DMA + prefetch of step k-1"),
+                (122, "cell_bwd B: dh GEMM (4 gates on 4 waves) + barrier")):
     print(f"   {name:58s} {buf[i]:8d}")
