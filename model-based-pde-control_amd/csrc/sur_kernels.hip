@@ -627,8 +627,10 @@ __device__ void rb_forward(const RBBuf& b, const float* const* w) {
 }
 
 // dout [cout][hout] -> din [cin][hin]; g1, g2, g3, xh: scratch of cout*hout floats each
+// need_din = false (the encoder's first block: its input is data): the two data-gradient GEMMs onto the block input are
+// skipped -- with cin = 1 they fill one row of every 16-row MFMA tile and were the longest phase of that block.
 __device__ void rb_backward(const RBBuf& b, const float* const* w, float* const* g, const float* dout, float* din,
-                            float* g1, float* g2, float* g3, float* xh, int sb = -1) {
+                            float* g1, float* g2, float* g3, float* xh, int sb = -1, bool need_din = true) {
 #ifdef SUR_STAMP
 #define RB_STAMP(i) do { if (sb >= 0) STAMP(sb + (i)); } while (0)
 #else
@@ -637,8 +639,13 @@ __device__ void rb_backward(const RBBuf& b, const float* const* w, float* const*
     act_ln_bwd(dout, b.s, b.cout, b.hout, w[SUR_RB_LN3_W], false, g1, xh, g[SUR_RB_LN3_W], g[SUR_RB_LN3_B]);
     RB_STAMP(0);
     // skip path
-    conv_bwd_weight<1>(g1, b.cout, b.in, b.cin, b.hin, b.stride, 0, g[SUR_RB_SKIP], nullptr, lower_half(), false);
-    conv_bwd_data<1>(g1, b.cout, b.hin, w[SUR_RB_SKIP], b.cin, b.stride, 0, din, false, upper_half(), true);
+    if (need_din) {
+        conv_bwd_weight<1>(g1, b.cout, b.in, b.cin, b.hin, b.stride, 0, g[SUR_RB_SKIP], nullptr, lower_half(), false);
+        conv_bwd_data<1>(g1, b.cout, b.hin, w[SUR_RB_SKIP], b.cin, b.stride, 0, din, false, upper_half(), true);
+    } else {
+        conv_bwd_weight<1>(g1, b.cout, b.in, b.cin, b.hin, b.stride, 0, g[SUR_RB_SKIP], nullptr, all_waves(), false);
+        // no barrier: the next phase reads g1 / a2pre and writes g2, xh and the LayerNorm accumulators only
+    }
     RB_STAMP(1);
     // residual path
     act_ln_bwd(g1, b.a2pre, b.cout, b.hout, w[SUR_RB_LN2_W], true, g2, xh, g[SUR_RB_LN2_W], g[SUR_RB_LN2_B]);
@@ -648,8 +655,12 @@ __device__ void rb_backward(const RBBuf& b, const float* const* w, float* const*
     RB_STAMP(3);
     act_ln_bwd(g3, b.a1pre, b.cout, b.hout, w[SUR_RB_LN1_W], true, g1, xh, g[SUR_RB_LN1_W], g[SUR_RB_LN1_B]);
     RB_STAMP(4);
-    conv_bwd_weight<3>(g1, b.cout, b.in, b.cin, b.hin, b.stride, 1, g[SUR_RB_CONV1], nullptr, lower_half(), false);
-    conv_bwd_data<3>(g1, b.cout, b.hin, w[SUR_RB_CONV1], b.cin, b.stride, 1, din, true, upper_half(), true);
+    if (need_din) {
+        conv_bwd_weight<3>(g1, b.cout, b.in, b.cin, b.hin, b.stride, 1, g[SUR_RB_CONV1], nullptr, lower_half(), false);
+        conv_bwd_data<3>(g1, b.cout, b.hin, w[SUR_RB_CONV1], b.cin, b.stride, 1, din, true, upper_half(), true);
+    } else {
+        conv_bwd_weight<3>(g1, b.cout, b.in, b.cin, b.hin, b.stride, 1, g[SUR_RB_CONV1], nullptr, all_waves(), true);
+    }
     RB_STAMP(5);
 #undef RB_STAMP
 }
@@ -932,15 +943,17 @@ __device__ __forceinline__ void enc_block_bwd_body(const EncBlockJob& j, int blk
     const int ws_out_off = blk == 1 ? p.c[1] * h1 : 0;      // where block 1 reads d loss / d its output (written by block 2)
     for (int m = wg; m < j.m; m += j.wg_count) {
         const float* rec = j.saved + (size_t)m * nsv;
-        // this block's input, its seven intermediates, the gradient wrt its output: all loads of a round in flight
+        const float* dsrc = blk == 2 ? j.dz + (size_t)m * a : j.ws + (size_t)m * nws + (blk == 1 ? ws_out_off : 0);
+        // this block's input, four of its seven intermediates, the gradient wrt its output.  record: skip | a1pre a1 a2pre | a2 | s | out
+        // (one loader with every load of the sample in flight and a single barrier measured 3 % SLOWER on the whole step than
+        // these four: 40 more live registers spill in a 128-VGPR kernel, and the co-resident workgroups cover the round trips)
         if (gm.in_saved_off < 0) lds_load(rb.in, j.x + (size_t)m * nin, nin);
         else lds_load_v4(rb.in, rec + gm.in_saved_off, nin >> 2);
-        lds_load_v4(rb.a1pre, rec + gm.saved_off + a, (3 * a) >> 2);      // record: skip | a1pre a1 a2pre | a2 | s | out
+        lds_load_v4(rb.a1pre, rec + gm.saved_off + a, (3 * a) >> 2);
         lds_load_v4(rb.s, rec + gm.saved_off + 5 * a, a >> 2);
-        const float* dsrc = blk == 2 ? j.dz + (size_t)m * a : j.ws + (size_t)m * nws + (blk == 1 ? ws_out_off : 0);
         lds_load_v4(dout, dsrc, a >> 2);
         STAMP(sbase + 2);
-        rb_backward(rb, v.w, v.g, dout, din, g1, g2, g3, xh, sbase + 3);
+        rb_backward(rb, v.w, v.g, dout, din, g1, g2, g3, xh, sbase + 3, blk > 0);
         if (blk > 0) {
             float* dst = j.ws + (size_t)m * nws + (blk == 2 ? ws_in_off : 0);
             for (int i = threadIdx.x; i < nin; i += blockDim.x) dst[i] = din[i];
@@ -2016,12 +2029,37 @@ template <int NP, typename Params>
 __device__ __forceinline__ void flush_grads_body(const Params& p, int psize, const sur_adam& adam, bool overwrite, int blk,
                                                  int nblk) {
     // block = FLUSH_COLS columns x FLUSH_RG row groups: each thread sums every FLUSH_RG-th row of its column, LDS combines
-    // the partials (a wave reads 2 rows x 128 contiguous bytes per load instruction).
+    // the partials (a wave reads 2 rows x 128 contiguous bytes per load instruction).  The kernel is a chain of memory
+    // round trips (rows -> LDS -> Adam state -> ticket), so whatever does not depend on the sum is fetched FIRST: the row
+    // group 0 threads -- the ones that finish a column -- locate their parameter and load its moments / weight before
+    // the row loop.
     __shared__ float part[FLUSH_RG][FLUSH_COLS + 1];
     const int col = threadIdx.x & (FLUSH_COLS - 1), rg = threadIdx.x / FLUSH_COLS;
     const int t = blk * FLUSH_COLS + col;
     const int step = adam.m ? *adam.step + 1 : 0;   // read before this block takes its ticket (see below)
     const float lr = adam.m ? *adam.lr : 0.0f;      // device scalar: a scheduler can change it between graph replays
+    const bool finisher = rg == 0 && t < psize;
+    float* gdst = nullptr;
+    float* wdst = nullptr;
+    float m_old = 0.0f, v_old = 0.0f, w_old = 0.0f, bc1 = 1.0f, bc2 = 1.0f;
+    if (finisher) {
+        int off = 0;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            if (t >= off && t < off + p.size[i]) {
+                gdst = p.g[i] + (t - off);
+                wdst = const_cast<float*>(p.w[i]) + (t - off);
+            }
+            off += p.size[i];
+        }
+        if (adam.m) {
+            m_old = adam.m[t];
+            v_old = adam.v[t];
+            w_old = *wdst;
+            bc1 = 1.0f - powf(adam.beta1, (float)step);
+            bc2 = 1.0f - powf(adam.beta2, (float)step);
+        }
+    }
     float acc = 0.0f;
     if (t < psize) {
         constexpr int U = 8;   // loads of a round all in flight before the first add / re-zero (same summation order)
@@ -2044,31 +2082,22 @@ __device__ __forceinline__ void flush_grads_body(const Params& p, int psize, con
     }
     part[rg][col] = acc;
     __syncthreads();
-    if (rg == 0 && t < psize) {
+    if (finisher) {
         float tot = 0.0f;
 #pragma unroll
         for (int i = 0; i < FLUSH_RG; ++i) tot += part[i][col];
-        int off = 0;
-#pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            if (t >= off && t < off + p.size[i]) {
-                if (adam.m) {
-                    p.g[i][t - off] = tot;
-                    const float m = adam.beta1 * adam.m[t] + (1.0f - adam.beta1) * tot;
-                    const float v = adam.beta2 * adam.v[t] + (1.0f - adam.beta2) * tot * tot;
-                    adam.m[t] = m;
-                    adam.v[t] = v;
-                    const float bc1 = 1.0f - powf(adam.beta1, (float)step), bc2 = 1.0f - powf(adam.beta2, (float)step);
-                    const float denom = sqrtf(v) / sqrtf(bc2) + adam.eps;
-                    float* w = const_cast<float*>(p.w[i]);
-                    w[t - off] -= (lr / bc1) * (m / denom);
-                } else if (overwrite) {
-                    p.g[i][t - off] = tot;
-                } else {
-                    p.g[i][t - off] += tot;
-                }
-            }
-            off += p.size[i];
+        if (adam.m) {
+            *gdst = tot;
+            const float m = adam.beta1 * m_old + (1.0f - adam.beta1) * tot;
+            const float v = adam.beta2 * v_old + (1.0f - adam.beta2) * tot * tot;
+            adam.m[t] = m;
+            adam.v[t] = v;
+            const float denom = sqrtf(v) / sqrtf(bc2) + adam.eps;
+            *wdst = w_old - (lr / bc1) * (m / denom);
+        } else if (overwrite) {
+            *gdst = tot;
+        } else {
+            *gdst += tot;
         }
     }
     if (adam.m) {   // the workgroup that takes the last ticket has, like every other, already read the step count

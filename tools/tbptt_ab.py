@@ -8,6 +8,9 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "model-based-pde-control_amd"))
 import torch  # noqa: E402
+from pdecontrol.surrogates import hipops  # noqa: E402
+if os.environ.get("SUR_LIB"):       # A/B of kernel builds: SUR_LIB=<path to a libsurrogate_hip variant>
+    hipops.LIB_PATH = os.path.abspath(os.environ["SUR_LIB"])
 from pdecontrol.surrogates.bench_tbptt import build_module, synthetic_batch  # noqa: E402
 from pdecontrol.surrogates.graph_step import GraphedTBPTTStep  # noqa: E402
 
