@@ -190,6 +190,23 @@ int sur_tbptt_delta_loss(void* stream, const float* states, long states_bstride,
                          float stdv, float* deltas, float* dd_all, float* hsteploss, float* loss, float* stats,
                          double* partial, unsigned int* ticket);
 
+/* The integration pass of sur_chunk_forward on its own (out_k = base_k + delta * (d_k * mul + add), surrogate.py:108-117):
+ * sur_chunk_forward skips it when called with out_all = NULL, so a caller that needs the integrated predictions of a chunk
+ * only for reporting (the last TBPTT chunk: nothing is rolled out from them) can queue it off its critical path. */
+int sur_chunk_integrate(void* stream, const sur_chunk_params* p, const float* states_t, const float* d_all, int k, int s, int b,
+                        float* out_all);
+
+/* sur_tbptt_delta_loss_range in two halves: _rows writes the `deltas` / `dd_all` rows [t_begin, t_end) and their partial sums
+ * and takes no ticket -- the backward pass can start from dd_all right away --, _finalize (one workgroup, after every row
+ * launch of the loss) reduces the partial sums into loss / hsteploss / stats.  A loss may mix _range launches (early
+ * chunks) with ONE _rows launch as long as _finalize follows them all. */
+int sur_tbptt_delta_loss_rows(void* stream, const float* states, long states_bstride, long states_tstride, const float* d_all,
+                              int b, int t, int n, float delta, float mean, float stdv, float* deltas, float* dd_all,
+                              float* hsteploss, float* loss, float* stats, double* partial, unsigned int* ticket, int t_begin,
+                              int t_end);
+int sur_tbptt_delta_loss_finalize(void* stream, int b, int t, int n, float* hsteploss, float* loss, float* stats, double* partial,
+                                  unsigned int* ticket);
+
 /* Fold partial-gradient rows [bases[j], bases[j] + counts[j]) of pack j (0: e0, 1: e1, 2: c2) into row dsts[j] of the same
  * buffer (dst += sum, fixed order; dst outside the folded range) and re-zero them.  A backward branch that ends early
  * (an early TBPTT chunk) folds its own rows, so the step's final sur_flush_all_grads reads one row per branch. */

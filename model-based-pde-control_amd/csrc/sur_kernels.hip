@@ -1042,11 +1042,14 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+__device__ void delta_loss_finish(int B, int T, int N, int nsplit, float* __restrict__ hsteploss, float* __restrict__ loss,
+                                  float* __restrict__ stats, double* __restrict__ partial, unsigned int* __restrict__ ticket);
+
 __global__ void __launch_bounds__(TPB)
 delta_loss_kernel(const float* __restrict__ states, long sb, long st, const float* __restrict__ d_all, int B, int T, int N, float delta,
                   float mean, float stdv, float* __restrict__ deltas, float* __restrict__ dd_all,
                   float* __restrict__ hsteploss, float* __restrict__ loss, float* __restrict__ stats,
-                  double* __restrict__ partial, unsigned int* __restrict__ ticket, int t0) {
+                  double* __restrict__ partial, unsigned int* __restrict__ ticket, int t0, int take_ticket) {
     __shared__ double red[TPB / 64][LOSS_NSUM];
     __shared__ bool last;
     // blockIdx.x = time step, blockIdx.y = slice of the B*N elements of that step; LOSS_UNROLL elements per
@@ -1100,12 +1103,21 @@ delta_loss_kernel(const float* __restrict__ states, long sb, long st, const floa
         for (int w = 0; w < TPB / 64; ++w) v += red[w][threadIdx.x];
         partial[((size_t)t * nsplit + blockIdx.y) * LOSS_NSUM + threadIdx.x] = v;
     }
+    if (!take_ticket) return;   // the caller finishes the loss with delta_loss_finalize_kernel, off its critical path
     __threadfence();
     __syncthreads();
     if (threadIdx.x == 0) last = (atomicAdd(ticket, 1u) == (unsigned)(T * nsplit - 1));
     __syncthreads();
     if (!last) return;
     __threadfence();
+    delta_loss_finish(B, T, N, nsplit, hsteploss, loss, stats, partial, ticket);
+}
+
+// fixed-order reduction of the (T-1) x nsplit partial sums: by the workgroup that arrived last, or by a launch of its own
+__device__ void delta_loss_finish(int B, int T, int N, int nsplit, float* __restrict__ hsteploss, float* __restrict__ loss,
+                                  float* __restrict__ stats, double* __restrict__ partial, unsigned int* __restrict__ ticket) {
+    const int per_t = B * N;
+    const double count = (double)per_t * (T - 1);
     // fixed-order reduction of the (T-1) x nsplit partial sums by the workgroup that arrived last.  The partials are
     // fetched with relaxed device-scope atomic loads, one partial per thread, so the loads overlap (a serial loop
     // of volatile loads cost ~20 us here).
@@ -1141,6 +1153,12 @@ delta_loss_kernel(const float* __restrict__ states, long sb, long st, const floa
         stats[3] = (float)sqrt(fmax(tsum[4] - count * m_dl * m_dl, 0.0) / (count - 1.0));
         *ticket = 0u;  // ready for the next launch (graph replay)
     }
+}
+
+__global__ void __launch_bounds__(TPB)
+delta_loss_finalize_kernel(int B, int T, int N, int nsplit, float* __restrict__ hsteploss, float* __restrict__ loss,
+                           float* __restrict__ stats, double* __restrict__ partial, unsigned int* __restrict__ ticket) {
+    delta_loss_finish(B, T, N, nsplit, hsteploss, loss, stats, partial, ticket);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2421,7 +2439,7 @@ int sur_chunk_saved_floats(const sur_chunk_params* p) {
 int sur_chunk_forward(void* stream, const sur_chunk_params* p, const float* xlat_t, const float* lstates_t,
                       const float* states_t, const float* h0, const float* c0, int hc_bstride, int k, int s, int b,
                       float* h_all, float* c_all, float* d_all, float* out_all, float* saved) {
-    if (!p || !xlat_t || !h0 || !c0 || !h_all || !c_all || !d_all || !out_all || k <= 0 || b <= 0 || s < 1 ||
+    if (!p || !xlat_t || !h0 || !c0 || !h_all || !c_all || !d_all || k <= 0 || b <= 0 || s < 1 ||
         !lstates_t || !states_t || hc_bstride < 0)
         return fail(-1, "sur_chunk_forward: bad argument (need K > 0, B > 0, S >= 1)");
     if (4 * p->hq > 64 * LN_MAX_EPL) return fail(-4, "sur_chunk_forward: N = %d too wide for the fused LayerNorm", 4 * p->hq);
@@ -2436,7 +2454,7 @@ int sur_chunk_forward(void* stream, const sur_chunk_params* p, const float* xlat
     const size_t lds_cell = sizeof(float) * (cell_fwd_act_floats(*p) + psize_lstm);
     const size_t lds_dec = sizeof(float) * (dec_act_floats(*p, false) + psize_dec);
     if (int rc = set_lds(dec_fwd_kernel, lds_dec, "decoder forward")) return rc;
-    const int m = k * b, n = 4 * p->hq;
+    const int m = k * b;
     const int chain_threads = cell_chain_threads(*p);
     auto launch_cell_fwd = [&](auto kernel) -> int {
         if (int rc = set_lds(kernel, lds_cell, "cell forward")) return rc;
@@ -2453,6 +2471,14 @@ int sur_chunk_forward(void* stream, const sur_chunk_params* p, const float* xlat
             hipLaunchKernelGGL(dec_fwd_kernel, dim3(m < 1024 ? m : 1024), dim3(TPB), lds_dec, (hipStream_t)stream, *p, h_all, m,
                                d_all, saved);
         }, "dec_fwd")) return rc;
+    if (!out_all) return 0;   // the caller integrates later / elsewhere (sur_chunk_integrate)
+    return sur_chunk_integrate(stream, p, states_t, d_all, k, s, b, out_all);
+}
+
+int sur_chunk_integrate(void* stream, const sur_chunk_params* p, const float* states_t, const float* d_all, int k, int s, int b,
+                        float* out_all) {
+    if (!p || !states_t || !d_all || !out_all || k <= 0 || b <= 0 || s < 1) return fail(-1, "sur_chunk_integrate: bad argument");
+    const int n = 4 * p->hq;
     return launch_checked([&] {
         hipLaunchKernelGGL(integrate_kernel, dim3((b * n + TPB - 1) / TPB), dim3(TPB), 0, (hipStream_t)stream, states_t, d_all, k,
                            s, b, n, p->delta, p->mul, p->add, out_all);
@@ -2661,7 +2687,7 @@ int sur_adam_apply(void* stream, const sur_encoder_params* e0, const sur_adam* a
 static int delta_loss_launch(void* stream, const float* states, long states_bstride, long states_tstride, const float* d_all, int b,
                              int t, int n, float delta, float mean, float stdv, float* deltas, float* dd_all, float* hsteploss,
                              float* loss, float* stats, double* partial, unsigned int* ticket, int t_begin, int t_end,
-                             const char* who) {
+                             const char* who, int take_ticket = 1) {
     if (!states || !d_all || !deltas || !hsteploss || !loss || !stats || !partial || !ticket || b <= 0 || t < 2 || n <= 0)
         return fail(-1, "%s: bad argument (need B > 0, T >= 2, N > 0)", who);
     if (t_begin < 0 || t_end > t || t_begin >= t_end) return fail(-1, "%s: time range [%d, %d) outside [0, %d)", who, t_begin, t_end, t);
@@ -2672,8 +2698,13 @@ static int delta_loss_launch(void* stream, const float* states, long states_bstr
     return launch_checked([&] {
         hipLaunchKernelGGL(delta_loss_kernel, dim3(t_end - t_begin, nsplit), dim3(TPB), 0, (hipStream_t)stream, states, states_bstride,
                            states_tstride, d_all, b, t, n, delta, mean,
-                           stdv, deltas, dd_all, hsteploss, loss, stats, partial, ticket, t_begin);
+                           stdv, deltas, dd_all, hsteploss, loss, stats, partial, ticket, t_begin, take_ticket);
     }, "delta_loss");
+}
+
+static int loss_nsplit(int b, int n) {
+    const int nsplit = (b * n + LOSS_UNROLL * TPB - 1) / (LOSS_UNROLL * TPB);
+    return nsplit < 1 ? 1 : (nsplit > LOSS_MAX_SPLIT ? LOSS_MAX_SPLIT : nsplit);
 }
 
 int sur_tbptt_delta_loss(void* stream, const float* states, long states_bstride, long states_tstride, const float* d_all, int b,
@@ -2690,6 +2721,25 @@ int sur_tbptt_delta_loss_range(void* stream, const float* states, long states_bs
                                int t_end) {
     return delta_loss_launch(stream, states, states_bstride, states_tstride, d_all, b, t, n, delta, mean, stdv, deltas, dd_all,
                              hsteploss, loss, stats, partial, ticket, t_begin, t_end, "sur_tbptt_delta_loss_range");
+}
+
+int sur_tbptt_delta_loss_rows(void* stream, const float* states, long states_bstride, long states_tstride, const float* d_all,
+                              int b, int t, int n, float delta, float mean, float stdv, float* deltas, float* dd_all,
+                              float* hsteploss, float* loss, float* stats, double* partial, unsigned int* ticket, int t_begin,
+                              int t_end) {
+    return delta_loss_launch(stream, states, states_bstride, states_tstride, d_all, b, t, n, delta, mean, stdv, deltas, dd_all,
+                             hsteploss, loss, stats, partial, ticket, t_begin, t_end, "sur_tbptt_delta_loss_rows", 0);
+}
+
+int sur_tbptt_delta_loss_finalize(void* stream, int b, int t, int n, float* hsteploss, float* loss, float* stats, double* partial,
+                                  unsigned int* ticket) {
+    if (!hsteploss || !loss || !stats || !partial || !ticket || b <= 0 || t < 2 || n <= 0)
+        return fail(-1, "sur_tbptt_delta_loss_finalize: bad argument");
+    const int nsplit = loss_nsplit(b, n);
+    return launch_checked([&] {
+        hipLaunchKernelGGL(delta_loss_finalize_kernel, dim3(1), dim3(TPB), 0, (hipStream_t)stream, b, t, n, nsplit, hsteploss, loss,
+                           stats, partial, ticket);
+    }, "delta_loss_finalize");
 }
 
 }  // extern "C"

@@ -75,6 +75,10 @@ SYMBOLS = (
     ("sur_adam_apply", [_fp, _EP, _AP, _EP, _AP, _CP, _AP]),
     ("sur_tbptt_delta_loss", [_fp, _fp, ctypes.c_long, ctypes.c_long, _fp, _i, _i, _i, ctypes.c_float, ctypes.c_float, ctypes.c_float, _fp, _fp, _fp, _fp,
                               _fp, _fp, _fp]),
+    ("sur_chunk_integrate", [_fp, _CP, _fp, _fp, _i, _i, _i, _fp]),
+    ("sur_tbptt_delta_loss_rows", [_fp, _fp, ctypes.c_long, ctypes.c_long, _fp, _i, _i, _i, ctypes.c_float, ctypes.c_float,
+                                   ctypes.c_float, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i]),
+    ("sur_tbptt_delta_loss_finalize", [_fp, _i, _i, _i, _fp, _fp, _fp, _fp, _fp]),
     ("sur_fold_rows", [_fp, _EP, _EP, _CP, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     ("sur_tbptt_delta_loss_range", [_fp, _fp, ctypes.c_long, ctypes.c_long, _fp, _i, _i, _i, ctypes.c_float, ctypes.c_float,
                                     ctypes.c_float, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i]),
@@ -832,10 +836,12 @@ class _Fork:
             self.main.wait_stream(self.stream)
 
 
-def _tbptt_forward(states, actions, owner, surrogate, tau, tbtt, after_chunk=None):
+def _tbptt_forward(states, actions, owner, surrogate, tau, tbtt, after_chunk=None, integrate_last=True):
     """The forward launches of a TBPTT pass (see ``_TBPTTFn``).  ``after_chunk(c, st)`` -- if given -- is called right
     after chunk ``c``'s rollout has been queued, with the pass's state so far (``st``: the namespace this function
-    returns): the pipelined training pass hangs that chunk's loss + backward branch there."""
+    returns): the pipelined training pass hangs that chunk's loss + backward branch there.  ``integrate_last`` = False
+    leaves the LAST chunk's predictions un-integrated (``st.out_all`` rows of that chunk unwritten): nothing is rolled out
+    from them, the caller queues ``sur_chunk_integrate`` off the critical path."""
     b, t_total, _, n = actions.shape
     cs, hq, ca = owner.chunk.c.cs, owner.chunk.c.hq, owner.chunk.c.ca
     dev = actions.device
@@ -931,7 +937,8 @@ def _tbptt_forward(states, actions, owner, surrogate, tau, tbtt, after_chunk=Non
             main.wait_event(lat_ready[c])    # this chunk's action latents (encoded on the side stream)
         _check(lib.sur_chunk_forward(_stream(), ctypes.byref(owner.chunk.c), _p(lactions_t[k0:k1]), _p(lstates[c]),
                                      _p(seeds[c]), _p(h0s[c]), _p(c0s[c]), 0 if c == 0 else s_lat, k, s_used, b,
-                                     _p(h_all), _p(c_all), _p(d_all[k0:k1]), _p(out_all[k0:k1]), _p(saved)))
+                                     _p(h_all), _p(c_all), _p(d_all[k0:k1]),
+                                     _p(out_all[k0:k1]) if (integrate_last or c < nchunks - 1) else None, _p(saved)))
         h_alls.append(h_all)
         c_alls.append(c_all)
         saveds.append(saved)
@@ -1105,9 +1112,16 @@ def fused_tbptt_train(surrogate, states, actions, tau, tbtt, delta, mean, stdv):
     def backward_of(c, st):
         k0, k1 = bounds[c]
         k = k1 - k0
-        _check(lib.sur_tbptt_delta_loss_range(_stream(), _p(states), states.stride(0), states.stride(1), _p(st.d_all), b,
-                                              t_total, n, float(delta), float(mean), float(stdv), _p(deltas), _p(dd_all),
-                                              _p(hstep), _p(loss), _p(stats), _p(partial), _p(ticket), k0, k1))
+        # the last chunk's loss rows are on the critical path: rows only there (the reduction to loss / statistics and the
+        # integration of its predictions follow on the side stream, `finish_last`)
+        loss_rows = lib.sur_tbptt_delta_loss_rows if c == nchunks - 1 else lib.sur_tbptt_delta_loss_range
+        _check(loss_rows(_stream(), _p(states), states.stride(0), states.stride(1), _p(st.d_all), b, t_total, n, float(delta),
+                         float(mean), float(stdv), _p(deltas), _p(dd_all), _p(hstep), _p(loss), _p(stats), _p(partial),
+                         _p(ticket), k0, k1))
+        if c == nchunks - 1:
+            rows_done = torch.cuda.Event()
+            rows_done.record(torch.cuda.current_stream(dev))
+            tail.append(rows_done)
         dxlat = torch.empty_like(st.lactions_t[k0:k1])
         dlst = torch.empty_like(st.lstates[c])
         work = _chunk_workspace(owner.chunk, k, b, dev)
@@ -1126,6 +1140,18 @@ def fused_tbptt_train(surrogate, states, actions, tau, tbtt, delta, mean, stdv):
         keep.extend((dxlat, dlst, work))
 
     pending = []     # (chunk, fork point) whose backward branch has not been issued yet
+    tail = []        # the event after the last chunk's loss rows
+
+    def finish_last(st):
+        """Side stream, after every branch: integrate the last chunk's predictions, reduce the loss partial sums."""
+        k0, k1 = bounds[-1]
+        fork = _Fork(side, after=tail[0])
+        with fork:
+            _check(lib.sur_chunk_integrate(_stream(), ctypes.byref(owner.chunk.c), _p(st.seeds[-1]), _p(st.d_all[k0:k1]), k1 - k0,
+                                           min(st.seeds[-1].shape[0], k1 - k0), b, _p(st.out_all[k0:k1])))
+            _check(lib.sur_tbptt_delta_loss_finalize(_stream(), b, t_total, n, _p(hstep), _p(loss), _p(stats), _p(partial),
+                                                     _p(ticket)))
+        forks.append(fork)
 
     def after_chunk(c, st):
         # chunk c-1's branch forks where chunk c-1's rollout ended but is issued only now, after chunk c's own forward
@@ -1143,7 +1169,8 @@ def fused_tbptt_train(surrogate, states, actions, tau, tbtt, delta, mean, stdv):
         point.record(torch.cuda.current_stream(dev))
         pending.append((c, point))
 
-    st = _tbptt_forward(states, actions, owner, surrogate, tau, tbtt, after_chunk=after_chunk)
+    st = _tbptt_forward(states, actions, owner, surrogate, tau, tbtt, after_chunk=after_chunk, integrate_last=False)
+    finish_last(st)
     for fork in forks:
         fork.join()
     for pack, extent in ((owner.state_enc, st_fold + 1), (owner.action_enc, act_fold + 1), (owner.chunk, chunk_fold + 1)):
