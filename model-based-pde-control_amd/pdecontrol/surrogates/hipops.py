@@ -873,7 +873,7 @@ def _tbptt_forward(states, actions, owner, surrogate, tau, tbtt, after_chunk=Non
     # the other action latents on the side stream: with `split`, forked AFTER the launches above (which fill the
     # device anyway) so that they run beside chunk 0's cell chain, which occupies only B of the 256 CUs
     fork_point = None
-    if split and nchunks > 1 and _INNER_FORKS:
+    if split and nchunks > 1 and _INNER_FORKS and (n >= 128 or torch.cuda.is_current_stream_capturing()):
         fork_point = torch.cuda.Event()
         fork_point.record(torch.cuda.current_stream(dev))
     fork = _Fork(side, worthwhile=n >= 128, after=fork_point)
