@@ -331,6 +331,26 @@ def test_n256_benchmarked_batch_b64_fused():
             np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=1e-2, atol=4e-5 * max(1.0, np.abs(ref).max()), err_msg=k)
 
 
+def test_n256_pipelined_pass_b64_against_reference_fixture():
+    """The captured step's pipelined pass at the bench's TBPTT headline (N = 256, B = 64, T = 20, Normalize scaling) against
+    the reference classes' CPU loss / per-step loss / gradients."""
+    from test_surrogate_host import N256_GOLDEN, build_n256, n256_batch
+    g = np.load(N256_GOLDEN)
+    dev = torch.device("cuda", 0)
+    m = build_n256(True, dev)
+    s, a = (t.to(dev) for t in n256_batch(64))
+    res = m._pipelined_training_step((s, a))
+    assert res is not None
+    torch.cuda.synchronize(dev)
+    rel = abs(res["loss"].item() - float(g["b64n_loss"])) / float(g["b64n_loss"])
+    assert rel < 1e-5, rel
+    np.testing.assert_allclose(res["hsteploss"].cpu().numpy(), g["b64n_hsteploss"], rtol=1e-4)
+    for k, p in m.surrogate.named_parameters():
+        if p.requires_grad:
+            ref = g["b64n_grad/" + k]
+            np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=1e-2, atol=4e-5 * max(1.0, np.abs(ref).max()), err_msg=k)
+
+
 def test_validation_and_test_step_on_gpu_against_reference_module():
     """validation_step / test_step with the module on the GPU (fused rollout) and env.rhs on the HIP hook (one batched call
     for all samples) against the arrays the reference's module produced on the CPU."""
