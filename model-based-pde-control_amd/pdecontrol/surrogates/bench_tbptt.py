@@ -161,11 +161,19 @@ def run_size(device, N, steps, warmup, B=64, with_plain=True, with_ensemble=True
     batch = synthetic_batch(B=B, N=N, device=device)
     res = {"N": N}
     res["hip_graph_fused"] = time_graphed(device, batch, steps * 4, warmup)
-    dt, _ = time_eager(build_module(device, N=N), batch, steps=steps, warmup=warmup)
-    res["eager_fused"] = {"value": B / dt, "ms_per_step": dt * 1e3, "steps": steps,
-                          "what": "training_step (fused HIP kernels) -> zero_grad -> backward -> torch.optim.Adam(fused=True): "
-                                  "the path pl.Trainer.fit drives by default (reference: pdecontrol/mbrl/mbrl.py:593)",
+    dt, _ = time_eager(build_module(device, N=N), batch, steps=steps * 2, warmup=warmup)
+    res["eager_fused"] = {"value": B / dt, "ms_per_step": dt * 1e3, "steps": steps * 2,
+                          "what": "training_step -> zero_grad -> backward -> PackAdam.step() in Lightning's closure order: the path "
+                                  "pl.Trainer.fit drives by default (reference: pdecontrol/mbrl/mbrl.py:593); forward + loss and "
+                                  "backward + gradient reduction are two replayed hipGraphs behind one autograd node "
+                                  "(graph_step.GraphedAutogradStep)",
                           "ratio_to_graphed": dt * 1e3 / res["hip_graph_fused"]["ms_per_step"]}
+    launch_by_launch = build_module(device, N=N)
+    launch_by_launch.split_graphs = False
+    dt, _ = time_eager(launch_by_launch, batch, steps=steps, warmup=warmup)
+    res["eager_fused_launch_by_launch"] = {"value": B / dt, "ms_per_step": dt * 1e3, "steps": steps,
+                                           "what": "the same with PDECONTROL_SPLIT_GRAPHS=0: ~25 ctypes launches + two autograd "
+                                                   "nodes per step from Python (host-bound)"}
     try:
         res["lightning_graphed"] = time_lightning_graphed(device, batch, steps * 2, warmup)
     except Exception as exc:

@@ -244,3 +244,128 @@ class _LendAdam:
     def __exit__(self, *exc):
         if self.step.adam_in_flush:
             self.step.module.surrogate._fused_packs.disable_adam()
+
+
+class _ReplayBackward(torch.autograd.Function):
+    """The autograd node behind the loss a ``GraphedAutogradStep`` returns: its backward replays the captured backward."""
+
+    @staticmethod
+    def forward(ctx, anchor, loss_static, step):
+        ctx.step = step
+        return loss_static.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.step.backward(g)
+        return None, None, None
+
+
+class GraphedAutogradStep:
+    """``training_step`` for Lightning's AUTOMATIC optimization (``pl.Trainer.fit``'s default, pdecontrol/mbrl/mbrl.py:593) as
+    two replayed hipGraphs behind one autograd node, for one batch shape:
+
+      forward()            copies the batch into static buffers, replays  [ TBPTT forward | delta loss ]  and returns
+                           training_step's dict; ``loss`` carries a grad_fn
+      loss.backward()      replays  [ every chunk's backward | encoder backward | gradient reduction ]  into the packs' flat
+                           gradient buffers and re-attaches their views to ``param.grad``
+      optimizer.step()     whatever Lightning holds (``hipops.PackAdam``: one launch)
+
+    Lightning's closure order (training_step -> zero_grad -> backward -> step), gradient clipping, accumulation
+    (``param.grad`` already defined: the captured "add" variant, or views + add for foreign tensors) and loss scaling
+    (the incoming gradient multiplies d loss / d deltas before the replay) keep their meaning; the ~0.8 ms of Python that the
+    launch-by-launch eager step costs per batch does not.  The chunks are not pipelined here (backward starts when Lightning
+    says so); ``GraphedTBPTTStep`` (``graphed=True``) is the fastest route."""
+
+    def __init__(self, module, batch_shape, action_shape=None, warmup=2):
+        from pdecontrol.surrogates import hipops
+        self.module = module
+        dev = next(module.surrogate.parameters()).device
+        assert dev.type == "cuda"
+        self.device = dev
+        tm = lambda shape: torch.zeros((shape[1], shape[0]) + tuple(shape[2:]), device=dev).transpose(0, 1)
+        self.states = tm(tuple(batch_shape))
+        self.actions = tm(tuple(action_shape or batch_shape))
+        (self.stream,) = hipops.pooled_streams(dev, 1, "capture")
+        consts = hipops.undscale_constants(module.undscaling)
+        args = (module.surrogate, self.states, self.actions, module.tau, module.tbtt, module.delta) + tuple(consts)
+        self.stream.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(self.stream), torch.no_grad():
+            for _ in range(warmup):                   # kernels, allocator, partial-row buffers: nothing may grow under capture
+                st, _res = hipops.fused_tbptt_forward_loss(*args)
+                hipops.fused_tbptt_backward(st, accumulate=False)
+        torch.cuda.current_stream(dev).wait_stream(self.stream)
+        torch.cuda.synchronize(dev)
+        self.g_fwd, self.g_bwd, self.g_bwd_acc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        pool = torch.cuda.graph_pool_handle()
+
+        def fwd():
+            with torch.no_grad():
+                return hipops.fused_tbptt_forward_loss(*args)
+
+        self._st, res = self._capture(self.g_fwd, fwd, pool)
+        self._capture(self.g_bwd, lambda: hipops.fused_tbptt_backward(self._st, accumulate=False), pool)
+        self._capture(self.g_bwd_acc, lambda: hipops.fused_tbptt_backward(self._st, accumulate=True), pool)
+        outputs, outdeltas, _hidden, loss, hsteploss, stats, deltas = res
+        self.loss = loss
+        self.result = {"hsteploss": hsteploss, "outputs": outputs, "actions": self.actions, "states": self.states,
+                       "outdeltas": outdeltas[:, :-1], "deltas": deltas}
+        self.logged = {"Train Loss": loss, "Train Mean Delta Output": stats[0], "Train Std. Delta Output": stats[1],
+                       "Train Mean Delta": stats[2], "Train Std. Delta": stats[3]}
+        self.packs = module.surrogate._fused_packs
+        self._key = self.packs.key
+
+    def _capture(self, graph, fn, pool):
+        gc.collect()
+        torch.cuda.synchronize(self.device)
+        was_enabled = gc.isenabled()
+        gc.disable()
+        try:
+            with torch.cuda.graph(graph, pool=pool, stream=self.stream):
+                out = fn()
+        finally:
+            if was_enabled:
+                gc.enable()
+        return out
+
+    def valid(self):
+        """False once the surrogate's parameters have been re-allocated (the graphs carry their addresses)."""
+        packs = getattr(self.module.surrogate, "_fused_packs", None)
+        return packs is self.packs and packs.key == type(packs)._key(self.module.surrogate, packs.n)
+
+    def forward(self, states, actions):
+        self.states.copy_(states, non_blocking=True)
+        self.actions.copy_(actions, non_blocking=True)
+        self.g_fwd.replay()
+        out = dict(self.result)
+        out["loss"] = _ReplayBackward.apply(self.packs.anchor, self.loss, self)
+        return out
+
+    def backward(self, g):
+        packs = self.packs.packs
+        self._st.dd_all.mul_(g)          # d loss / d deltas of the captured loss times the incoming gradient
+        state = []
+        for pack in packs:
+            grads = [p.grad for p in pack.params]
+            if all(x is None for x in grads):
+                state.append("none")
+            elif pack.grads_are_own_views():
+                state.append("own")
+            else:
+                state.append("foreign")
+        if all(s == "own" for s in state):
+            self.g_bwd_acc.replay()      # accumulation onto what the previous backward left in the flat buffers
+            return
+        keep = [pack.gflat.clone() if s == "own" else None for pack, s in zip(packs, state)]
+        self.g_bwd.replay()
+        for pack, s, k in zip(packs, state, keep):
+            if s == "none":
+                for p, view in zip(pack.params, pack._gviews):
+                    p.grad = view
+            elif s == "own":
+                pack.gflat.add_(k)
+            else:
+                for p, view in zip(pack.params, pack._gviews):
+                    if p.grad is None:
+                        p.grad = view.clone()
+                    else:
+                        p.grad.add_(view)

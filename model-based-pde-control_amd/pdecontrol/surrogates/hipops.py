@@ -180,16 +180,23 @@ class _Pack:
         views = self._gviews
         return views is not None and all(p.grad is v for p, v in zip(self.params, views))
 
+    def own_flat_grads(self):
+        """Point the kernel's gradient addresses at the pack-owned flat buffer (created on first use); param.grad untouched."""
+        if self.gflat is None:
+            self.gflat = torch.zeros(self.psize, device=self.params[0].device, dtype=torch.float32)
+            self._gviews, off = [], 0
+            for p in self.params:
+                self._gviews.append(self.gflat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+        for i, view in enumerate(self._gviews):
+            self.c.g[i] = view.data_ptr()
+
     def resolve_grads(self):
         """Gradient addresses, taken when the reduction is about to be launched.  Sets ``self.overwrite``."""
         grads = [p.grad for p in self.params]
         if all(g is None for g in grads):
             if self.gflat is None:
-                self.gflat = torch.empty(self.psize, device=self.params[0].device, dtype=torch.float32)
-                self._gviews, off = [], 0
-                for p in self.params:
-                    self._gviews.append(self.gflat[off:off + p.numel()].view_as(p))
-                    off += p.numel()
+                self.own_flat_grads()
             for i, (p, view) in enumerate(zip(self.params, self._gviews)):
                 p.grad = view
                 self.c.g[i] = view.data_ptr()
@@ -378,6 +385,17 @@ class FusedPacks:
             return
         for pack in dirty:
             pack.flush()
+
+    def flush_into_flat(self, accumulate):
+        """Reduce the partial rows into the packs' OWN flat gradient buffers (``gflat``; overwrite, or add when
+        ``accumulate``), whatever ``param.grad`` currently is: the captured backward of the split-graph step, whose caller
+        re-attaches the views to ``param.grad`` after each replay (``hand_out_flat_grads``)."""
+        self._flush_queued = False
+        for pack in self.packs:
+            pack.own_flat_grads()
+            pack.dirty = False
+        _check(load().sur_flush_all_grads(_stream(), ctypes.byref(self.state_enc.c), None, ctypes.byref(self.action_enc.c), None,
+                                          ctypes.byref(self.chunk.c), None, 0 if accumulate else 7))
 
     # -- optimizer inside the flush launches ---------------------------------------------------------------------
     def set_lr(self, lr):
@@ -972,65 +990,69 @@ class _TBPTTFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dd_all, _dout, _dh, _dc):
-        owner, bounds = ctx.owner, ctx.bounds
-        b, t_total, n, nchunks = ctx.dims
-        actions_t, lactions_t, seeds, lstates, h0s, c0s, h_alls, c_alls, saveds, asaved, ssaved = ctx.saved
-        lib = load()
-        dev = actions_t.device
         if dd_all is None:
             return (None,) * 7
-        dd_all = dd_all.contiguous()
-        dxlat_all = torch.empty_like(lactions_t)
-        rows = max(b, CHUNK_ROWS)
-        owner.chunk.ensure_rows(nchunks * rows)
-        enc_rows = [min(ENCODER_ROWS, ls.shape[0] * b) for ls in lstates]
-        owner.state_enc.ensure_rows(sum(enc_rows))
-        owner.refresh_partials()
-        dlsts = [torch.empty_like(ls) for ls in lstates]
-        s_lat = owner.chunk.c.cs * owner.chunk.c.hq
-        if nchunks <= MAX_SPANS:
-            # every chunk in the same three launches (decoder backward, cell chains, dx + weight gradients): no forks
-            h_all_u, c_all_u, saved_u = ctx.unified
-            spans = (ChunkSpan * nchunks)()
-            for c, (k0, k1) in enumerate(bounds):
-                spans[c] = ChunkSpan(k0, k1, min(seeds[c].shape[0], k1 - k0), lstates[c].data_ptr(), h0s[c].data_ptr(),
-                                     c0s[c].data_ptr(), 0 if c == 0 else s_lat, dlsts[c].data_ptr())
-            rows_all = max(nchunks * b, min(nchunks * rows, t_total * b))
-            owner.chunk.ensure_rows(rows_all)
-            owner.refresh_partials()
-            work = _chunk_workspace(owner.chunk, t_total, b, dev)
-            _check(lib.sur_chunks_backward(_stream(), ctypes.byref(owner.chunk.c), nchunks, spans, _p(lactions_t), _p(h_all_u),
-                                           _p(c_all_u), _p(dd_all), t_total, b, _p(dxlat_all), 0, rows_all, _p(saved_u), _p(work)))
-        else:
-            streams = _side_streams(owner, dev, nchunks)
-            forks = []
-            for c, (k0, k1) in enumerate(bounds):
-                fork = _Fork(streams[c])
-                with fork:
-                    work = _chunk_workspace(owner.chunk, k1 - k0, b, dev)
-                    _check(lib.sur_chunk_backward(_stream(), ctypes.byref(owner.chunk.c), _p(lactions_t[k0:k1]), _p(lstates[c]),
-                                                  _p(h0s[c]), _p(c0s[c]), 0 if c == 0 else s_lat, _p(h_alls[c]), _p(c_alls[c]),
-                                                  _p(dd_all[k0:k1]), None, None, None, k1 - k0, min(seeds[c].shape[0], k1 - k0), b,
-                                                  _p(dxlat_all[k0:k1]), _p(dlsts[c]), None, None, c * rows, rows, _p(saveds[c]),
-                                                  _p(work)))
-                    for t in (work, dlsts[c]):
-                        t.record_stream(fork.stream)
-                forks.append(fork)
-            for fork in forks:
-                fork.join()
-        # every encoder backward of the step in launches of up to three jobs: all their workgroups are dispatched
-        # together (as separate launches the long action-encoder job queued behind a state-encoder job), longest first
-        jobs = [(owner.action_enc, actions_t, dxlat_all, t_total * b, 0, min(ENCODER_ROWS, owner.action_enc.c.rows), asaved)]
-        row0 = 0
-        for c in range(nchunks):
-            jobs.append((owner.state_enc, seeds[c], dlsts[c], lstates[c].shape[0] * b, row0, enc_rows[c], ssaved[c]))
-            row0 += enc_rows[c]
-        for j0 in range(0, len(jobs), 3):
-            _encoder_backward_multi(lib, jobs[j0:j0 + 3])
-        for pack in owner.packs:
-            pack.dirty = True
-        owner.schedule_flush()
+        _tbptt_backward(ctx.owner, ctx.bounds, ctx.dims, ctx.saved, ctx.unified, dd_all.contiguous())
+        ctx.owner.schedule_flush()
         return (None,) * 7
+
+
+def _tbptt_backward(owner, bounds, dims, saved_state, unified, dd_all):
+    """The backward launches of a TBPTT pass for d loss / d deltas = ``dd_all`` [T,B,1,N] (every chunk in the same three
+    chunk launches when there are at most MAX_SPANS of them, then all encoder backward jobs); marks the packs dirty."""
+    b, t_total, n, nchunks = dims
+    actions_t, lactions_t, seeds, lstates, h0s, c0s, h_alls, c_alls, saveds, asaved, ssaved = saved_state
+    lib = load()
+    dev = actions_t.device
+    dxlat_all = torch.empty_like(lactions_t)
+    rows = max(b, CHUNK_ROWS)
+    owner.chunk.ensure_rows(nchunks * rows)
+    enc_rows = [min(ENCODER_ROWS, ls.shape[0] * b) for ls in lstates]
+    owner.state_enc.ensure_rows(sum(enc_rows))
+    owner.refresh_partials()
+    dlsts = [torch.empty_like(ls) for ls in lstates]
+    s_lat = owner.chunk.c.cs * owner.chunk.c.hq
+    if nchunks <= MAX_SPANS:
+        # every chunk in the same three launches (decoder backward, cell chains, dx + weight gradients): no forks
+        h_all_u, c_all_u, saved_u = unified
+        spans = (ChunkSpan * nchunks)()
+        for c, (k0, k1) in enumerate(bounds):
+            spans[c] = ChunkSpan(k0, k1, min(seeds[c].shape[0], k1 - k0), lstates[c].data_ptr(), h0s[c].data_ptr(),
+                                 c0s[c].data_ptr(), 0 if c == 0 else s_lat, dlsts[c].data_ptr())
+        rows_all = max(nchunks * b, min(nchunks * rows, t_total * b))
+        owner.chunk.ensure_rows(rows_all)
+        owner.refresh_partials()
+        work = _chunk_workspace(owner.chunk, t_total, b, dev)
+        _check(lib.sur_chunks_backward(_stream(), ctypes.byref(owner.chunk.c), nchunks, spans, _p(lactions_t), _p(h_all_u),
+                                       _p(c_all_u), _p(dd_all), t_total, b, _p(dxlat_all), 0, rows_all, _p(saved_u), _p(work)))
+    else:
+        streams = _side_streams(owner, dev, nchunks)
+        forks = []
+        for c, (k0, k1) in enumerate(bounds):
+            fork = _Fork(streams[c])
+            with fork:
+                work = _chunk_workspace(owner.chunk, k1 - k0, b, dev)
+                _check(lib.sur_chunk_backward(_stream(), ctypes.byref(owner.chunk.c), _p(lactions_t[k0:k1]), _p(lstates[c]),
+                                              _p(h0s[c]), _p(c0s[c]), 0 if c == 0 else s_lat, _p(h_alls[c]), _p(c_alls[c]),
+                                              _p(dd_all[k0:k1]), None, None, None, k1 - k0, min(seeds[c].shape[0], k1 - k0), b,
+                                              _p(dxlat_all[k0:k1]), _p(dlsts[c]), None, None, c * rows, rows, _p(saveds[c]),
+                                              _p(work)))
+                for t in (work, dlsts[c]):
+                    t.record_stream(fork.stream)
+            forks.append(fork)
+        for fork in forks:
+            fork.join()
+    # every encoder backward of the step in launches of up to three jobs: all their workgroups are dispatched
+    # together (as separate launches the long action-encoder job queued behind a state-encoder job), longest first
+    jobs = [(owner.action_enc, actions_t, dxlat_all, t_total * b, 0, min(ENCODER_ROWS, owner.action_enc.c.rows), asaved)]
+    row0 = 0
+    for c in range(nchunks):
+        jobs.append((owner.state_enc, seeds[c], dlsts[c], lstates[c].shape[0] * b, row0, enc_rows[c], ssaved[c]))
+        row0 += enc_rows[c]
+    for j0 in range(0, len(jobs), 3):
+        _encoder_backward_multi(lib, jobs[j0:j0 + 3])
+    for pack in owner.packs:
+        pack.dirty = True
 
 
 def fused_tbptt(surrogate, states, actions, tau, tbtt):
@@ -1183,3 +1205,36 @@ def fused_tbptt_train(surrogate, states, actions, tau, tbtt, delta, mean, stdv):
     del keep[:]
     return (st.out_all.transpose(0, 1), st.d_all.transpose(0, 1), (st.h_alls[-1][-1], st.c_alls[-1][-1]), loss, hstep, stats,
             deltas)
+
+
+def fused_tbptt_forward_loss(surrogate, states, actions, tau, tbtt, delta, mean, stdv):
+    """Forward launches of a TBPTT pass + the one-launch delta loss, WITHOUT autograd: the first half of the split-graph
+    step (``graph_step.GraphedAutogradStep``).  Returns (state for ``fused_tbptt_backward``, result tuple
+    (outputs, outdeltas, (H, C), loss, hsteploss, stats, true deltas))."""
+    b, t_total, _, n = actions.shape
+    owner = packs_for(surrogate, n, b)
+    dev = actions.device
+    if states.stride(3) != 1:
+        states = states.contiguous()
+    st = _tbptt_forward(states, actions, owner, surrogate, tau, tbtt)
+    new = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)
+    deltas, hstep, loss, stats = new(b, t_total - 1, 1, n), new(t_total - 1), new(), new(4)
+    st.dd_all = new(t_total, b, 1, n)
+    scratch = owner.loss_scratch.get(t_total)
+    if scratch is None:
+        scratch = (torch.empty(40 * t_total, device=dev, dtype=torch.float64), torch.zeros(1, device=dev, dtype=torch.int32))
+        owner.loss_scratch[t_total] = scratch
+    _check(load().sur_tbptt_delta_loss(_stream(), _p(states), states.stride(0), states.stride(1), _p(st.d_all), b, t_total, n,
+                                       float(delta), float(mean), float(stdv), _p(deltas), _p(st.dd_all), _p(hstep), _p(loss),
+                                       _p(stats), _p(scratch[0]), _p(scratch[1])))
+    st.owner = owner
+    return st, (st.out_all.transpose(0, 1), st.d_all.transpose(0, 1), (st.h_alls[-1][-1], st.c_alls[-1][-1]), loss, hstep, stats,
+                deltas)
+
+
+def fused_tbptt_backward(st, accumulate=False):
+    """Second half of the split-graph step: the backward launches from ``st.dd_all`` (scaled in place by the caller when the
+    incoming gradient is not 1) and the gradient reduction into the packs' flat buffers."""
+    saved = (st.actions_t, st.lactions_t, st.seeds, st.lstates, st.h0s, st.c0s, st.h_alls, st.c_alls, st.saveds, st.asaved, st.ssaved)
+    _tbptt_backward(st.owner, st.bounds, (st.b, st.t_total, st.n, st.nchunks), saved, (st.h_all_u, st.c_all_u, st.saved_u), st.dd_all)
+    st.owner.flush_into_flat(accumulate)

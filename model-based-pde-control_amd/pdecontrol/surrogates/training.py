@@ -46,6 +46,9 @@ class PDETrainingModule(pl.LightningModule):
                  lr: float = 1e-03, lr_gamma: float = 1.0, step_size: int = 25, graphed: bool = None, **kwargs):
         super().__init__()
         self.graphed = (os.environ.get("PDECONTROL_GRAPHED", "0") == "1") if graphed is None else bool(graphed)
+        # automatic optimization: forward and backward replayed as two captured graphs (PDECONTROL_SPLIT_GRAPHS=0 opts out)
+        self.split_graphs = os.environ.get("PDECONTROL_SPLIT_GRAPHS", "1") != "0"
+
         if self.graphed:
             self.automatic_optimization = False   # Lightning: training_step owns backward + optimizer step
         self.surrogate, self.loss, self.tstep, self.delta, self.env = surrogate, loss, tstep, delta, env
@@ -154,7 +157,39 @@ class PDETrainingModule(pl.LightningModule):
         states = batch[0]
         if self.graphed and states.is_cuda:
             return self._graphed_training_step(batch)
+        if self.split_graphs and states.is_cuda and torch.is_grad_enabled():
+            out = self._split_graph_training_step(batch)
+            if out is not None:
+                return out
         return self._eager_training_step(batch, bidx)
+
+    def _split_graph_training_step(self, batch):
+        """training_step under Lightning's automatic optimization as two replayed hipGraphs behind one autograd node
+        (``graph_step.GraphedAutogradStep``): forward + loss now, backward + gradient reduction when the caller runs
+        ``loss.backward()``.  None when the configuration is not the controller's (then the launch-by-launch path runs)."""
+        from pdecontrol.surrogates import ops
+        states, actions, *_ = batch
+        if not (ops.use_fused(states) and isinstance(self.surrogate, AutoRegPDESurrogate)) or self.training_mode != "delta":
+            return None
+        if not (isinstance(self.loss, torch.nn.MSELoss) and self.loss.reduction == "none"):
+            return None
+        from pdecontrol.surrogates import hipops
+        if hipops.undscale_constants(self.undscaling) is None or states.dtype != torch.float32 or states.shape[2] != 1:
+            return None
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        if not all(p.requires_grad for n, p in self.surrogate.named_parameters() if not n.endswith((".H0", ".C0"))):
+            return None     # a frozen sub-module: the captured backward would still write its gradients
+        from pdecontrol.surrogates.graph_step import GraphedAutogradStep
+        key = (tuple(states.shape), tuple(actions.shape))
+        cache = self.__dict__.setdefault("_split_steps", {})
+        step = cache.get(key)
+        if step is None or not step.valid():
+            step = cache[key] = GraphedAutogradStep(self, key[0], key[1])
+        out = step.forward(states, actions)
+        for name, value in step.logged.items():
+            self.log(name, value, on_step=False, on_epoch=True)
+        return out
 
     def _eager_training_step(self, batch, bidx):
         states, actions, *_ = batch

@@ -126,6 +126,49 @@ def test_pipelined_pass_equals_autograd_pass(tbtt, T):
             np.testing.assert_allclose(q.grad.cpu().numpy(), p.grad.cpu().numpy(), rtol=1e-4, atol=2e-6 * scale, err_msg=k)
 
 
+def test_split_graph_step_is_what_automatic_optimization_drives():
+    """The default CUDA route of training_step under Lightning's automatic optimization -- forward + loss and backward +
+    gradient reduction as two replayed graphs behind one autograd node (graph_step.GraphedAutogradStep) -- against the
+    launch-by-launch fused step: closure order (training_step -> zero_grad(set_to_none) -> backward -> step), a scaled loss,
+    gradient accumulation over two batches, a second batch shape, torch's own Adam on the handed-out gradients."""
+    from pdecontrol.surrogates.bench_tbptt import build_module, synthetic_batch
+    dev = torch.device("cuda", 0)
+    b16, b8 = synthetic_batch(B=16, device=dev), synthetic_batch(B=8, device=dev)
+    split, plain = build_module(dev), build_module(dev)
+    plain.split_graphs = False
+    assert split.split_graphs
+    opts = [m.configure_optimizers()[0][0] for m in (split, plain)]
+    losses = [[], []]
+    for k in range(6):
+        batch = b8 if k in (2, 3) else b16
+        for i, (m, o) in enumerate(zip((split, plain), opts)):
+            out = m.training_step(batch, 0)
+            o.zero_grad(set_to_none=True)
+            (out["loss"] * (0.5 if k == 4 else 1.0)).backward()
+            o.step()
+            losses[i].append(out["loss"].item())
+    assert len(split.__dict__["_split_steps"]) == 2 and "_split_steps" not in plain.__dict__
+    np.testing.assert_allclose(losses[0], losses[1], rtol=2e-5)
+    for (name, p), q in zip(split.surrogate.named_parameters(), plain.surrogate.parameters()):
+        np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), rtol=1e-4, atol=2e-6, err_msg=name)
+    # accumulation: two backward passes onto the same gradients, no zero_grad in between; then torch's Adam on them
+    for m in (split, plain):
+        for p in m.surrogate.parameters():
+            p.grad = None
+        for batch in (b16, b16):
+            m.training_step(batch, 0)["loss"].backward()
+    for (name, p), q in zip(split.surrogate.named_parameters(), plain.surrogate.parameters()):
+        if q.grad is None:           # H0 / C0: not trainable
+            assert p.grad is None
+            continue
+        scale = max(1.0, q.grad.abs().max().item())
+        np.testing.assert_allclose(p.grad.cpu().numpy(), q.grad.cpu().numpy(), rtol=1e-4, atol=2e-6 * scale, err_msg=name)
+    ref = {n: p.detach().clone() for n, p in split.surrogate.named_parameters()}
+    adam = torch.optim.Adam(split.surrogate.parameters(), lr=1e-3)
+    adam.step()
+    assert any(not torch.equal(p, ref[n]) for n, p in split.surrogate.named_parameters())
+
+
 @pytest.mark.parametrize("fused", [False, True])
 def test_hip_graph_step_equals_eager_training(fused):
     """Graph replay == eager training in pytorch-lightning's closure order (training_step -> zero_grad(set_to_none)
