@@ -332,6 +332,9 @@ class GraphedAutogradStep:
         packs = getattr(self.module.surrogate, "_fused_packs", None)
         return packs is self.packs and packs.key == type(packs)._key(self.module.surrogate, packs.n)
 
+    def all_trainable(self):
+        return all(p.requires_grad for pack in self.packs.packs for p in pack.params)
+
     def forward(self, states, actions):
         self.states.copy_(states, non_blocking=True)
         self.actions.copy_(actions, non_blocking=True)

@@ -178,14 +178,16 @@ class PDETrainingModule(pl.LightningModule):
             return None
         if torch.cuda.is_current_stream_capturing():
             return None
-        if not all(p.requires_grad for n, p in self.surrogate.named_parameters() if not n.endswith((".H0", ".C0"))):
-            return None     # a frozen sub-module: the captured backward would still write its gradients
         from pdecontrol.surrogates.graph_step import GraphedAutogradStep
         key = (tuple(states.shape), tuple(actions.shape))
         cache = self.__dict__.setdefault("_split_steps", {})
         step = cache.get(key)
         if step is None or not step.valid():
+            if not all(p.requires_grad for n, p in self.surrogate.named_parameters() if not n.endswith((".H0", ".C0"))):
+                return None     # a frozen sub-module: the captured backward would still write its gradients
             step = cache[key] = GraphedAutogradStep(self, key[0], key[1])
+        elif not step.all_trainable():
+            return None
         out = step.forward(states, actions)
         for name, value in step.logged.items():
             self.log(name, value, on_step=False, on_epoch=True)
