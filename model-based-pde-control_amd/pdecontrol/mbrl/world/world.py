@@ -23,6 +23,8 @@ collation.  Values are those of the host path (same kernels as the fused rollout
 """
 from typing import Any, Callable, Sequence
 
+import os
+
 import numpy as np
 import torch
 from torch.utils.data import Dataset, RandomSampler
@@ -132,6 +134,62 @@ class _DeviceWorldState:
             for h, t in zip(hid, new):
                 h.copy_(t)
 
+    # -- the reset's warm-up rollout as a second captured graph -------------------------------------------------
+    def capture_reset(self, states, actions):
+        """Capture [every member's warm-up rollout over the given window | per-row pick | in-place state update] for
+        windows of this shape (reference: world.py:113-131 runs it eagerly at every reset, i.e. every ``horizon`` steps).
+        The trajectories' current state and hidden state are preserved."""
+        from pdecontrol.surrogates.graph_step import capture_graph
+        from pdecontrol.surrogates.hipops import pooled_streams
+        dev, tstep = self.device, self.world.tstep
+        self.rs_states, self.rs_actions = states.detach().clone(), actions.detach().clone()
+        times, targets = tstep * torch.arange(actions.size(1)), tstep * actions.size(1)
+
+        def run():
+            with torch.no_grad():
+                outs = []
+                for sur, hid in zip(self.members, self.hidden):
+                    r = sur.rollout(states=self.rs_states, actions=self.rs_actions, hidden=None, times=times, targets=targets)
+                    outs.append(r.outputs)
+                    for h, new in zip(hid, r.hidden):
+                        h.copy_(new)
+                new_state = outs[0] if len(outs) == 1 else torch.stack(outs, dim=0)[self.chosen_f.to(torch.long), self.rows]
+                self.state.copy_(new_state)
+
+        keep = (self.state.clone(), [tuple(h.clone() for h in hid) for hid in self.hidden], self.h2d_dev.clone())
+        (stream,) = pooled_streams(dev, 1, "capture")
+        stream.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(stream):
+            for _ in range(2):
+                run()
+        self.reset_graph = torch.cuda.CUDAGraph()
+        capture_graph(self.reset_graph, run, stream)
+        torch.cuda.current_stream(dev).wait_stream(stream)
+        self.state.copy_(keep[0])
+        for hid, saved in zip(self.hidden, keep[1]):
+            for h, sv in zip(hid, saved):
+                h.copy_(sv)
+        self.h2d_dev.copy_(keep[2])
+
+    def can_replay_reset(self, states, actions):
+        return (getattr(self, "reset_graph", None) is not None and states.shape == self.rs_states.shape
+                and actions.shape == self.rs_actions.shape and states.dtype == self.rs_states.dtype)
+
+    def replay_reset(self, states, actions):
+        """The captured warm-up rollout on a new window batch; the ensemble's per-row member draw is the one
+        PDEEnsemble.rollout makes (surrogate.py:46), made here so the global NumPy stream advances identically."""
+        b = self.b
+        self.rs_states.copy_(states, non_blocking=True)
+        self.rs_actions.copy_(actions, non_blocking=True)
+        if self.ensemble is not None:
+            chosen = np.random.choice(self.ensemble.elite_idx, size=b)
+            self.h2d_host[b * self.act_elems:].copy_(torch.from_numpy(np.asarray(chosen, dtype=np.float32)))
+            self.chosen_f.copy_(self.h2d_host[b * self.act_elems:], non_blocking=True)
+        self.reset_graph.replay()
+
+    def host_obs(self):
+        return self.state.detach().squeeze(1).cpu().numpy()
+
     def step(self, host_actions):
         w, b = self.world, self.b
         self.h2d_host[:b * self.act_elems].copy_(torch.from_numpy(host_actions.reshape(-1)))
@@ -174,17 +232,19 @@ class _DeviceStartingStates:
         self.cum = starting.cumulative_sizes
 
     def next_batch(self):
-        import bisect
-        idx = next(self.batches)
+        idx = np.asarray(next(self.batches), dtype=np.int64)
         L = self.length
+        cum = np.asarray(self.cum, dtype=np.int64)
+        which = np.searchsorted(cum, idx, side="right")              # ConcatDataset's bisect_right, for the whole batch
+        local = idx - np.where(which > 0, cum[np.maximum(which - 1, 0)], 0)
         rows = np.empty((len(idx), L), dtype=np.int64)
-        for j, i in enumerate(idx):
-            d = bisect.bisect_right(self.cum, i)
+        for d in np.unique(which):                                     # at most length + 1 window lengths
+            sel = which == d
             sub = self.ds.datasets[d]
-            key, start = sub.locate(i - (self.cum[d - 1] if d > 0 else 0))
-            first = self.store.starts[key] + start
+            keys, starts = sub.locate_many(local[sel])
+            first = np.fromiter((self.store.starts[k] for k in keys), dtype=np.int64, count=len(keys)) + starts
             pos = np.maximum(np.arange(L) - (L - sub.length), 0)      # left padding repeats the window's first step
-            rows[j] = first + pos
+            rows[sel] = first[:, None] + pos[None, :]
         flat = torch.from_numpy(rows.reshape(-1)).to(self.device)
         shape = (len(idx), L)
         out = [t.index_select(0, flat).reshape(shape + tuple(t.shape[1:])) for t in self.store.tensors]
@@ -203,6 +263,7 @@ class WorldVecEnv(BaseWorldVecEnv):
                          horizon, tstep)
         self.batched_reward_func = batched_reward_func
         self.device_resident = device_resident     # None: decide at the first reset (GPU + fused kernels + batched reward)
+        self.capture_reset = os.environ.get("PDECONTROL_WORLD_CAPTURE_RESET", "1") != "0"   # device path: reset = a graph replay
         self._dev = None
         self._dev_starting = None
         # spaces as seen through the replay->world transforms (stransf is their inverse)
@@ -247,18 +308,25 @@ class WorldVecEnv(BaseWorldVecEnv):
                 self.timesteps = steps[:, -1].numpy()  # env step counter after the warm-up window
             times = self.tstep * torch.arange(actions.size(1))
             targets = self.tstep * actions.size(1)
-            self.output: ModelRollout = self.surrogate.rollout(states=states.to(dev), actions=actions.to(dev),
-                                                                hidden=None, times=times, targets=targets)
-            if self._use_device_path():
-                hiddens = self.output.hidden if _members(self.surrogate)[1] is not None else [self.output.hidden]
-                if self._dev is None:
-                    self._dev = _DeviceWorldState(self, self.output.outputs, hiddens)
-                else:
-                    self._dev.load(self.output.outputs, hiddens)
+            states, actions = states.to(dev), actions.to(dev)
+            if self._dev is not None and self._dev.can_replay_reset(states, actions):
+                self._dev.replay_reset(states, actions)     # the warm-up rollout of every member: one graph replay
+                self.output = None
+            else:
+                self.output: ModelRollout = self.surrogate.rollout(states=states, actions=actions, hidden=None, times=times,
+                                                                    targets=targets)
+                if self._use_device_path():
+                    hiddens = self.output.hidden if _members(self.surrogate)[1] is not None else [self.output.hidden]
+                    if self._dev is None:
+                        self._dev = _DeviceWorldState(self, self.output.outputs, hiddens)
+                    else:
+                        self._dev.load(self.output.outputs, hiddens)
+                    if self.capture_reset:
+                        self._dev.capture_reset(states, actions)
         self.simulated = 0
         self.tmp = None
         self.surrogate.train()
-        obs = self._host_obs()
+        obs = self._dev.host_obs() if self._dev is not None else self._host_obs()
         self._host_cache = obs
         if kwargs.get("return_info", False):
             return obs, {"step": self.timesteps.copy()}

@@ -71,6 +71,8 @@ def test_world_env_device_resident_against_reference():
                  world_kwargs={"batched_reward_func": lambda env: env.batched_reward_func})
     world = sc.run.last_world
     assert world._dev is not None and world._dev_starting is not None, "device-resident path did not engage"
+    # the scenario's second reset (after `horizon` = 3 steps) replayed the captured warm-up rollout
+    assert getattr(world._dev, "reset_graph", None) is not None and world.output is None
     _compare(rec, g)
 
 
