@@ -303,6 +303,9 @@ class GraphedAutogradStep:
                 return hipops.fused_tbptt_forward_loss(*args)
 
         self._st, res = self._capture(self.g_fwd, fwd, pool)
+        # the backward graphs read d loss / d deltas times the incoming gradient from a buffer of their own: the forward
+        # graph's output stays intact, so backward() may run more than once per forward (retain_graph)
+        self._st.dd_in = torch.zeros_like(self._st.dd_all)
         self._capture(self.g_bwd, lambda: hipops.fused_tbptt_backward(self._st, accumulate=False), pool)
         self._capture(self.g_bwd_acc, lambda: hipops.fused_tbptt_backward(self._st, accumulate=True), pool)
         outputs, outdeltas, _hidden, loss, hsteploss, stats, deltas = res
@@ -345,7 +348,7 @@ class GraphedAutogradStep:
 
     def backward(self, g):
         packs = self.packs.packs
-        self._st.dd_all.mul_(g)          # d loss / d deltas of the captured loss times the incoming gradient
+        torch.mul(self._st.dd_all, g, out=self._st.dd_in)   # d loss / d deltas of the captured loss times the incoming gradient
         state = []
         for pack in packs:
             grads = [p.grad for p in pack.params]

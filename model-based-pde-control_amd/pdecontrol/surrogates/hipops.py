@@ -571,7 +571,6 @@ class _EncoderFn(torch.autograd.Function):
         else:
             _check(load().sur_encoder_backward(_stream(), ctypes.byref(ctx.pack.c), _p(x), _p(dz.contiguous()), x.shape[0],
                                                _p(dx), 0, min(ENCODER_ROWS, ctx.pack.c.rows), _p(ctx.fwd_saved)))
-        ctx.fwd_saved = None
         ctx.pack.dirty = True
         ctx.owner.schedule_flush()
         return dx, None, None, None
@@ -645,7 +644,6 @@ class _ChunkFn(torch.autograd.Function):
                                          ctx.pack.c.cs * ctx.pack.c.hq, _p(h_all), _p(c_all), _p(dd_all), _p(dout_all), _p(dh_all), _p(dc_all), k,
                                          lstates_t.shape[0], b, _p(dxlat), _p(dlst), _p(dh0), _p(dc0), 0, rows,
                                          _p(ctx.fwd_saved), _p(work)))
-        ctx.fwd_saved = None
         ctx.pack.dirty = True
         ctx.owner.schedule_flush()
         return dxlat, dlst, None, dh0, dc0, None, None, None
@@ -676,7 +674,7 @@ class _DeltaLossFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_loss, *_):
-        dd, ctx.dd = ctx.dd, None
+        dd = ctx.dd                      # kept: backward may run again through a retained graph
         if dd is None or g_loss is None:
             return None, None, None, None, None, None
         if g_loss.data_ptr() == _UNIT_GRADS.get(g_loss.device, (None, 0))[1]:
@@ -1233,8 +1231,11 @@ def fused_tbptt_forward_loss(surrogate, states, actions, tau, tbtt, delta, mean,
 
 
 def fused_tbptt_backward(st, accumulate=False):
-    """Second half of the split-graph step: the backward launches from ``st.dd_all`` (scaled in place by the caller when the
-    incoming gradient is not 1) and the gradient reduction into the packs' flat buffers."""
+    """Second half of the split-graph step: the backward launches from ``st.dd_in`` (= ``st.dd_all`` times the incoming
+    gradient, written by the caller; ``st.dd_all`` itself when absent) and the gradient reduction into the packs' flat
+    buffers."""
     saved = (st.actions_t, st.lactions_t, st.seeds, st.lstates, st.h0s, st.c0s, st.h_alls, st.c_alls, st.saveds, st.asaved, st.ssaved)
-    _tbptt_backward(st.owner, st.bounds, (st.b, st.t_total, st.n, st.nchunks), saved, (st.h_all_u, st.c_all_u, st.saved_u), st.dd_all)
+    dd = getattr(st, "dd_in", None)      # the caller's (scaled) copy of d loss / d deltas, when it keeps st.dd_all pristine
+    _tbptt_backward(st.owner, st.bounds, (st.b, st.t_total, st.n, st.nchunks), saved, (st.h_all_u, st.c_all_u, st.saved_u),
+                    st.dd_all if dd is None else dd)
     st.owner.flush_into_flat(accumulate)

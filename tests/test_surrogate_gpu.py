@@ -163,6 +163,17 @@ def test_split_graph_step_is_what_automatic_optimization_drives():
             continue
         scale = max(1.0, q.grad.abs().max().item())
         np.testing.assert_allclose(p.grad.cpu().numpy(), q.grad.cpu().numpy(), rtol=1e-4, atol=2e-6 * scale, err_msg=name)
+    # backward twice through the same loss (retain_graph): the second pass adds the same gradients again
+    for m in (split, plain):
+        for p in m.surrogate.parameters():
+            p.grad = None
+        loss = m.training_step(b16, 0)["loss"] * 0.25
+        loss.backward(retain_graph=True)
+        loss.backward()
+    for (name, p), q in zip(split.surrogate.named_parameters(), plain.surrogate.parameters()):
+        if q.grad is not None:
+            scale = max(1.0, q.grad.abs().max().item())
+            np.testing.assert_allclose(p.grad.cpu().numpy(), q.grad.cpu().numpy(), rtol=1e-4, atol=2e-6 * scale, err_msg=name)
     ref = {n: p.detach().clone() for n, p in split.surrogate.named_parameters()}
     adam = torch.optim.Adam(split.surrogate.parameters(), lr=1e-3)
     adam.step()
