@@ -461,18 +461,28 @@ def main():
                 out["burgers_fno"] = {"error": f"{type(exc).__name__}: {exc}"}
     if dist is not None and not args.no_tbptt:
         # data-parallel surrogate step at N = 256: B = 64 sequences per rank, one flat-bucket all-reduce per step
+        ddp, err = None, None
         try:
             from pdecontrol.surrogates import bench_tbptt
             with torch.cuda.stream(torch.cuda.Stream(device=dev)):
-                dt_ddp, in_sync, loss_ddp, nbytes = bench_tbptt.run_ddp(dev, N=256)
-            td = torch.tensor([dt_ddp], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-            dist.all_reduce(td, op=dist.ReduceOp.MAX)
+                ddp = bench_tbptt.run_ddp(dev, N=256)
+        except Exception as exc:  # never lose the KS line to the secondary measurement
+            err = f"{type(exc).__name__}: {exc}"
+        # every rank reaches the same collectives whatever happened above: a rank that failed must not leave the others
+        # waiting in the timing reduction
+        cdev = dev if backend == "nccl" else "cpu"
+        ok = torch.tensor([0.0 if ddp is None else 1.0], dtype=torch.float64, device=cdev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        td = torch.tensor([0.0 if ddp is None else ddp[0]], dtype=torch.float64, device=cdev)
+        dist.all_reduce(td, op=dist.ReduceOp.MAX)
+        if float(ok.item()) == 1.0:
+            _dt, in_sync, loss_ddp, nbytes = ddp
             out["tbptt"] = {"unit": "seqs/s", "value": n_gpus * 64 / float(td.item()), "ms_per_step": float(td.item()) * 1e3,
                             "scaling": "weak", "B_per_rank": 64, "N": 256, "ranks_in_sync": in_sync, "loss": loss_ddp,
                             "exchange": f"one all-reduce of the flat {nbytes}-byte fp32 gradient bucket per step",
-                            "path": "fused HIP kernels, fwd/bwd hipGraph + all-reduce + Adam hipGraph"}
-        except Exception as exc:  # never lose the KS line to the secondary measurement
-            out["tbptt"] = {"error": f"{type(exc).__name__}: {exc}"}
+                            "path": "fused HIP kernels, fwd/bwd hipGraph (chunks pipelined) + all-reduce + Adam hipGraph"}
+        else:
+            out["tbptt"] = {"error": err or "the data-parallel step failed on another rank"}
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
