@@ -78,6 +78,7 @@ class _DeviceWorldState:
         from pdecontrol.surrogates.hipops import pooled_streams
         self.world = world
         self.members, self.ensemble = _members(world.surrogate)
+        self.signature = self._signature()
         dev = outputs.device
         self.device = dev
         b = outputs.shape[0]
@@ -108,6 +109,17 @@ class _DeviceWorldState:
         for hid, saved in zip(self.hidden, keep[1]):
             for h, sv in zip(hid, saved):
                 h.copy_(sv)
+
+    def _signature(self):
+        """What the captured launches carry by value: the members' parameter addresses and delta-scaling constants."""
+        from pdecontrol.surrogates import hipops
+        return [(next(m.parameters()).data_ptr(), hipops.scaling_signature(m)) for m in self.members]
+
+    def valid(self):
+        from pdecontrol.surrogates import hipops
+        now = self._signature()
+        return len(now) == len(self.signature) and all(a[0] == b[0] and hipops.same_signature(a[1], b[1])
+                                                       for a, b in zip(self.signature, now))
 
     def _advance_nograd(self):
         with torch.no_grad():
@@ -309,6 +321,8 @@ class WorldVecEnv(BaseWorldVecEnv):
             times = self.tstep * torch.arange(actions.size(1))
             targets = self.tstep * actions.size(1)
             states, actions = states.to(dev), actions.to(dev)
+            if self._dev is not None and not self._dev.valid():
+                self._dev = None     # retrained / re-scaled members (mbrl.py:597-602): the captured graphs are stale
             if self._dev is not None and self._dev.can_replay_reset(states, actions):
                 self._dev.replay_reset(states, actions)     # the warm-up rollout of every member: one graph replay
                 self.output = None

@@ -137,9 +137,23 @@ class GraphedTBPTTStep:
         self.adam_in_flush = False
         self._adam_state = None
         self.logged = {}
+        from pdecontrol.surrogates import hipops
+        self._scaling = hipops.scaling_signature(module.surrogate, getattr(module, "undscaling", None))
+        self._ptr0 = next(module.surrogate.parameters()).data_ptr()
         self._prepare(warmup)
         if capture:
             self._capture()
+
+    def valid(self):
+        """False once what the captured launches carry by value has changed: the parameters' addresses, or the delta
+        scaling statistics (re-fitted between the controller's training rounds, mbrl.py:597-602)."""
+        from pdecontrol.surrogates import hipops
+        params = self.shared._params
+        first = next(self.module.surrogate.parameters())
+        if not params or first is not params[0] or first.data_ptr() != self._ptr0:
+            return False
+        return hipops.same_signature(self._scaling, hipops.scaling_signature(self.module.surrogate,
+                                                                             getattr(self.module, "undscaling", None)))
 
     @property
     def lr(self):
@@ -316,6 +330,7 @@ class GraphedAutogradStep:
                        "Train Mean Delta": stats[2], "Train Std. Delta": stats[3]}
         self.packs = module.surrogate._fused_packs
         self._key = self.packs.key
+        self._scaling = hipops.scaling_signature(module.surrogate, module.undscaling)
 
     def _capture(self, graph, fn, pool):
         gc.collect()
@@ -331,9 +346,13 @@ class GraphedAutogradStep:
         return out
 
     def valid(self):
-        """False once the surrogate's parameters have been re-allocated (the graphs carry their addresses)."""
+        """False once the surrogate's parameters have been re-allocated or the delta scaling statistics re-fitted (the graphs
+        carry addresses and constants by value)."""
+        from pdecontrol.surrogates import hipops
         packs = getattr(self.module.surrogate, "_fused_packs", None)
-        return packs is self.packs and packs.key == type(packs)._key(self.module.surrogate, packs.n)
+        if packs is not self.packs or packs.key != type(packs)._key(self.module.surrogate, packs.n):
+            return False
+        return hipops.same_signature(self._scaling, hipops.scaling_signature(self.module.surrogate, self.module.undscaling))
 
     def all_trainable(self):
         return all(p.requires_grad for pack in self.packs.packs for p in pack.params)

@@ -286,6 +286,39 @@ def _dscale_constants(dscaling):
     raise SurrogateHipError("fused rollout supports dscaling = identity or Normalize(scalar stats).Inverse only")
 
 
+def scaling_signature(surrogate, undscaling=None):
+    """What the scaling constants baked into captured launches depend on.  The controller re-fits the delta statistics
+    between training rounds (``update_delta_transform``, pdecontrol/mbrl/mbrl.py:597-602: ``Normalize.reset()`` +
+    ``update()`` on the SAME object that the surrogate's ``dscaling`` and the module's ``undscaling`` wrap), so a captured
+    graph carries stale (mean, std) afterwards: every graph cache compares this signature (``same_signature``) and
+    re-captures when it has changed.  Tensors are held by reference and compared by identity (``update`` assigns new ones)."""
+    from pdegym.common import transforms as T
+    sig = []
+    for tr in (getattr(surrogate, "dscaling", None), undscaling):
+        inner = getattr(tr, "transform", None)
+        norm = inner if isinstance(inner, T.Normalize) else getattr(inner, "transf", None)
+        if isinstance(norm, T.Normalize):
+            sig.append((norm, norm.mean, norm.var, norm.count, norm.epsilon))
+        else:
+            sig.append((type(tr).__name__, type(inner).__name__))
+    return sig
+
+
+def same_signature(a, b):
+    if a is None or b is None or len(a) != len(b):
+        return False
+    for x, y in zip(a, b):
+        if len(x) != len(y):
+            return False
+        for u, v in zip(x, y):
+            if isinstance(u, torch.Tensor) or isinstance(v, torch.Tensor) or not isinstance(u, (int, float, str)):
+                if u is not v:
+                    return False
+            elif u != v:
+                return False
+    return True
+
+
 def undscale_constants(undscaling):
     """(mean, std) such that undscaling(x) == (x - mean) / std for the two forms the controller builds
     (mbrl.py:168-171): identity, or a Normalize with scalar statistics.  None for anything else."""

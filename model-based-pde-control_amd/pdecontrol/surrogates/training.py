@@ -238,7 +238,7 @@ class PDETrainingModule(pl.LightningModule):
         states, actions, *_ = batch
         key = (tuple(states.shape), tuple(actions.shape))
         cache = self.__dict__.setdefault("_graphed_steps", {})
-        if key not in cache:
+        if key not in cache or not cache[key].valid():
             # one process per GPU with an initialised process group: the captured step must exchange gradients
             # (forward/backward graph -> one flat-bucket all-reduce -> Adam graph), never train the ranks apart silently
             dist = torch.distributed

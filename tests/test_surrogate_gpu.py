@@ -180,6 +180,41 @@ def test_split_graph_step_is_what_automatic_optimization_drives():
     assert any(not torch.equal(p, ref[n]) for n, p in split.surrogate.named_parameters())
 
 
+def test_refitted_delta_statistics_invalidate_the_captured_graphs():
+    """The controller re-fits the delta Normalize between training rounds (mbrl.py:597-602) on the object the surrogate's
+    dscaling and the module's undscaling share; captured launches carry (mean, std) by value, so every graph cache must
+    notice and re-capture: split-graph route, graphed route and launch-by-launch step agree before and after."""
+    from pdecontrol.surrogates.bench_tbptt import build_module, synthetic_batch
+    dev = torch.device("cuda", 0)
+    batch = synthetic_batch(B=8, device=dev)
+    split, graphed, plain = build_module(dev), build_module(dev), build_module(dev)
+    plain.split_graphs = False
+
+    def losses():
+        out = []
+        for m in (split, plain):
+            for p in m.surrogate.parameters():
+                p.grad = None
+            res = m.training_step(batch, 0)
+            res["loss"].backward()
+            out.append((res["loss"].item(), torch.cat([p.grad.reshape(-1) for p in m.surrogate.parameters() if p.grad is not None])))
+        out.append((graphed.fused_step(batch, lr=0.0)["loss"].item(), None))     # lr = 0: parameters stay equal
+        return out
+
+    first = losses()
+    assert abs(first[0][0] - first[1][0]) < 2e-5 * abs(first[1][0]) and abs(first[2][0] - first[1][0]) < 2e-5 * abs(first[1][0])
+    for m in (split, graphed, plain):
+        norm = m.undscaling.transform
+        norm.reset()
+        norm.update(torch.linspace(-3.0, 5.0, 64).reshape(64, 1, 1))
+    second = losses()
+    assert abs(second[1][0] - first[1][0]) > 1e-2 * abs(first[1][0]), "the new statistics must change the loss"
+    assert abs(second[0][0] - second[1][0]) < 2e-5 * abs(second[1][0]), (second[0][0], second[1][0])
+    assert abs(second[2][0] - second[1][0]) < 2e-5 * abs(second[1][0]), (second[2][0], second[1][0])
+    scale = second[1][1].abs().max().item()
+    assert (second[0][1] - second[1][1]).abs().max().item() < 1e-4 * scale
+
+
 @pytest.mark.parametrize("fused", [False, True])
 def test_hip_graph_step_equals_eager_training(fused):
     """Graph replay == eager training in pytorch-lightning's closure order (training_step -> zero_grad(set_to_none)
