@@ -55,6 +55,12 @@ class EnsembleTBPTTStep:
             for g in self.members:
                 g.logged = dict(g.module.__dict__.pop("_graph_logged", {}))
 
+    def valid(self):
+        """False once a member's captured launches are stale (parameters moved, delta statistics re-fitted between the
+        controller's training rounds: ``GraphedTBPTTStep.valid``) -- build a new EnsembleTBPTTStep then; the Adam state
+        belongs to the surrogates and carries over."""
+        return all(g.valid() for g in self.members)
+
     def __len__(self):
         return len(self.members)
 
