@@ -307,3 +307,21 @@ def test_validation_and_test_step_match_reference_module():
     from pdegym.kuramoto import KuramotoSivashinskyEnv
     module, g = build_eval_module(KuramotoSivashinskyEnv(_stepper_cls=OracleStepper))
     check_eval_steps(module, g)
+
+
+def test_scaling_signature_notices_refitted_delta_statistics():
+    """Graph caches compare ``hipops.scaling_signature`` (host logic, no GPU): the controller's ``update_delta_transform``
+    (mbrl.py:597-602: reset() + update() on the shared Normalize) must change it, an untouched transform must not."""
+    from pdecontrol.surrogates import hipops
+    from pdecontrol.surrogates.bench_tbptt import build_module
+    m = build_module("cpu")
+    a = hipops.scaling_signature(m.surrogate, m.undscaling)
+    assert hipops.same_signature(a, hipops.scaling_signature(m.surrogate, m.undscaling))
+    norm = m.undscaling.transform
+    norm.reset()
+    norm.update(torch.linspace(-1.0, 2.0, 32).reshape(32, 1, 1))
+    b = hipops.scaling_signature(m.surrogate, m.undscaling)
+    assert not hipops.same_signature(a, b)
+    assert hipops.same_signature(b, hipops.scaling_signature(m.surrogate, m.undscaling))
+    # the surrogate's dscaling wraps the same Normalize object: both entries changed
+    assert a[0][0] is a[1][0] and b[0][1] is not a[0][1]

@@ -59,3 +59,12 @@ if world._dev_starting is not None:
         world._dev_starting.next_batch()
     torch.cuda.synchronize()
     print(f"  of which next_batch (index rule + gathers + transforms): {(time.perf_counter() - t0) / 30 * 1e3:.3f} ms")
+if "cprofile" in sys.argv:
+    import cProfile
+    import pstats
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(200):
+        world.step(acts)
+    pr.disable()
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
