@@ -51,9 +51,16 @@ struct ks_handle {
     float* d_phi = nullptr;     // [E,N] staging for host phi
     float* d_act = nullptr;     // [E,n_act]
     float* d_F = nullptr;       // [n_act,N]
-    float* d_obs = nullptr;     // [E,N]
-    double* d_ssq = nullptr;    // [E]
-    int* d_status = nullptr;    // [E]
+    // step outputs: ONE device block [ obs E*N f32 | ssq E f64 | status E i32 ] and a pinned host mirror of it, so that the
+    // host-boundary entries (ks_step / ks_step_actions / ks_step_rows) fetch everything with one asynchronous copy
+    // instead of three (or 3 per row) pageable ones
+    char* d_out = nullptr;
+    char* h_out = nullptr;      // pinned
+    size_t out_bytes = 0, off_ssq = 0, off_status = 0;
+    float* h_act = nullptr;     // pinned staging of the actions, [E,n_act]
+    float* d_obs = nullptr;     // [E,N]   (inside d_out)
+    double* d_ssq = nullptr;    // [E]     (inside d_out)
+    int* d_status = nullptr;    // [E]     (inside d_out)
     int* d_ids = nullptr;       // [E]
     double* d_rows = nullptr;   // [E,N] staging for ks_set_state_rows / ks_rhs
     unsigned* d_flag = nullptr; // selftest
@@ -219,10 +226,18 @@ int ks_create(int device, int num_envs, int N, double L, double dt, ks_handle** 
     } while (0)
     KS_ALLOC(h->d_u, en * sizeof(double));
     KS_ALLOC(h->d_phi, en * sizeof(float));
-    KS_ALLOC(h->d_obs, en * sizeof(float));
+    h->off_ssq = (en * sizeof(float) + 255) / 256 * 256;
+    h->off_status = h->off_ssq + (size_t)num_envs * sizeof(double);
+    h->out_bytes = h->off_status + (size_t)num_envs * sizeof(int);
+    KS_ALLOC(h->d_out, h->out_bytes);
+    h->d_obs = reinterpret_cast<float*>(h->d_out);
+    h->d_ssq = reinterpret_cast<double*>(h->d_out + h->off_ssq);
+    h->d_status = reinterpret_cast<int*>(h->d_out + h->off_status);
+    if (hipHostMalloc((void**)&h->h_out, h->out_bytes, hipHostMallocDefault) != hipSuccess) {
+        ks_destroy(h);
+        return fail(KS_ERR_HIP, "hipHostMalloc(%zu) failed", h->out_bytes);
+    }
     KS_ALLOC(h->d_rows, en * sizeof(double));
-    KS_ALLOC(h->d_ssq, num_envs * sizeof(double));
-    KS_ALLOC(h->d_status, num_envs * sizeof(int));
     KS_ALLOC(h->d_ids, num_envs * sizeof(int));
     KS_ALLOC(h->d_flag, sizeof(unsigned));
 #undef KS_ALLOC
@@ -244,10 +259,11 @@ int ks_destroy(ks_handle* h) {
     if (!h) return KS_OK;
     DeviceGuard g(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void* bufs[] = {h->d_u, h->d_phi, h->d_act, h->d_F, h->d_obs, h->d_ssq, h->d_status, h->d_ids, h->d_rows,
-                    h->d_flag};
+    void* bufs[] = {h->d_u, h->d_phi, h->d_act, h->d_F, h->d_out, h->d_ids, h->d_rows, h->d_flag};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
+    if (h->h_out) (void)hipHostFree(h->h_out);
+    if (h->h_act) (void)hipHostFree(h->h_act);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return KS_OK;
@@ -311,6 +327,9 @@ int ks_set_forcing(ks_handle* h, const float* F_host, int n_act) {
     h->d_act = nullptr;
     KS_HIP(hipMalloc((void**)&h->d_F, sizeof(float) * (size_t)n_act * h->N));
     KS_HIP(hipMalloc((void**)&h->d_act, sizeof(float) * (size_t)n_act * h->E));
+    if (h->h_act) (void)hipHostFree(h->h_act);
+    h->h_act = nullptr;
+    KS_HIP(hipHostMalloc((void**)&h->h_act, sizeof(float) * (size_t)n_act * h->E, hipHostMallocDefault));
     KS_HIP(hipMemcpyAsync(h->d_F, F_host, sizeof(float) * (size_t)n_act * h->N, hipMemcpyHostToDevice, h->stream));
     KS_HIP(hipStreamSynchronize(h->stream));
     h->n_act = n_act;
@@ -354,23 +373,34 @@ int ks_state_device_ptr(ks_handle* h, double** d_u) {
     return KS_OK;
 }
 
+constexpr size_t PINNED_OBS_LIMIT = 512 * 1024;
+
+// the step outputs of ALL envs into the pinned mirror: one copy of the whole block, or of its [ssq | status] tail only
+static int fetch_outputs(ks_handle* h, bool with_obs) {
+    const size_t from = with_obs ? 0 : h->off_ssq;
+    KS_HIP(hipMemcpyAsync(h->h_out + from, h->d_out + from, h->out_bytes - from, hipMemcpyDeviceToHost, h->stream));
+    KS_HIP(hipStreamSynchronize(h->stream));
+    return KS_OK;
+}
+
 static int step_common(ks_handle* h, const float* d_phi, const float* d_act, const int* d_ids, int n_rows,
                        long n_substeps, float* obs_f32, double* ssq_sum, int* status) {
     int rc = do_step(h, d_phi, d_act, d_ids, n_rows, n_substeps, obs_f32 ? h->d_obs : nullptr,
                      ssq_sum ? h->d_ssq : nullptr, status ? h->d_status : nullptr);
     if (rc != KS_OK) return rc;
-    const int rows = d_ids ? n_rows : h->E;
     if (!d_ids) {
-        if (obs_f32)
-            KS_HIP(hipMemcpyAsync(obs_f32, h->d_obs, sizeof(float) * (size_t)rows * h->N, hipMemcpyDeviceToHost,
-                                  h->stream));
-        if (ssq_sum)
-            KS_HIP(hipMemcpyAsync(ssq_sum, h->d_ssq, sizeof(double) * rows, hipMemcpyDeviceToHost, h->stream));
-        if (status)
-            KS_HIP(hipMemcpyAsync(status, h->d_status, sizeof(int) * rows, hipMemcpyDeviceToHost, h->stream));
+        // small observation blocks ride in the pinned mirror with the reward sums (one copy, one sync: 0.20 -> 0.16 ms per
+        // step at 1024 x 64); large ones go straight into the caller's buffer -- the extra host memcpy of 4 MB costs more
+        // than the runtime's own staged pageable copy (4096 x 256: 1.00 vs 1.12 ms)
+        const size_t obs_bytes = sizeof(float) * (size_t)h->E * h->N;
+        const bool direct_obs = obs_f32 && obs_bytes > PINNED_OBS_LIMIT;
+        if (direct_obs) KS_HIP(hipMemcpyAsync(obs_f32, h->d_obs, obs_bytes, hipMemcpyDeviceToHost, h->stream));
+        if (int rc2 = fetch_outputs(h, obs_f32 != nullptr && !direct_obs)) return rc2;
+        if (obs_f32 && !direct_obs) memcpy(obs_f32, h->h_out, obs_bytes);
+        if (ssq_sum) memcpy(ssq_sum, h->h_out + h->off_ssq, sizeof(double) * h->E);
+        if (status) memcpy(status, h->h_out + h->off_status, sizeof(int) * h->E);
     }
-    KS_HIP(hipStreamSynchronize(h->stream));
-    return KS_OK;
+    return KS_OK;   // listed rows: ks_step_rows fetches the block (and synchronises) itself
 }
 
 int ks_step(ks_handle* h, const float* phi_host, long n_substeps, float* obs_f32, double* ssq_sum, int* status) {
@@ -390,8 +420,9 @@ int ks_step_actions(ks_handle* h, const float* actions_host, long n_substeps, fl
     if (!h || !actions_host) return fail(KS_ERR_INVALID, "NULL argument");
     if (!h->d_F) return fail(KS_ERR_INVALID, "ks_step_actions needs ks_set_forcing first");
     DeviceGuard g(h->device);
-    KS_HIP(hipMemcpyAsync(h->d_act, actions_host, sizeof(float) * (size_t)h->E * h->n_act, hipMemcpyHostToDevice,
-                          h->stream));
+    const size_t abytes = sizeof(float) * (size_t)h->E * h->n_act;
+    memcpy(h->h_act, actions_host, abytes);     // the previous step's copy has completed: every entry synchronises
+    KS_HIP(hipMemcpyAsync(h->d_act, h->h_act, abytes, hipMemcpyHostToDevice, h->stream));
     return step_common(h, nullptr, h->d_act, nullptr, 0, n_substeps, obs_f32, ssq_sum, status);
 }
 
@@ -407,19 +438,18 @@ int ks_step_rows(ks_handle* h, const int* env_ids_host, int n, long n_substeps, 
     KS_HIP(hipMemcpyAsync(h->d_ids, env_ids_host, sizeof(int) * n, hipMemcpyHostToDevice, h->stream));
     int rc = step_common(h, nullptr, nullptr, h->d_ids, n, n_substeps, obs_f32, ssq_sum, status);
     if (rc != KS_OK) return rc;
-    // outputs are indexed by env id on the device; hand them back compacted in list order
+    // outputs are indexed by env id on the device; fetch the block once and hand the listed rows back in list order
+    if (int rc2 = fetch_outputs(h, obs_f32 != nullptr)) return rc2;
     const size_t row = sizeof(float) * (size_t)h->N;
+    const float* hobs = reinterpret_cast<const float*>(h->h_out);
+    const double* hssq = reinterpret_cast<const double*>(h->h_out + h->off_ssq);
+    const int* hst = reinterpret_cast<const int*>(h->h_out + h->off_status);
     for (int i = 0; i < n; ++i) {
         const int e = env_ids_host[i];
-        if (obs_f32)
-            KS_HIP(hipMemcpyAsync(obs_f32 + (size_t)i * h->N, h->d_obs + (size_t)e * h->N, row,
-                                  hipMemcpyDeviceToHost, h->stream));
-        if (ssq_sum)
-            KS_HIP(hipMemcpyAsync(ssq_sum + i, h->d_ssq + e, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        if (status)
-            KS_HIP(hipMemcpyAsync(status + i, h->d_status + e, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        if (obs_f32) memcpy(obs_f32 + (size_t)i * h->N, hobs + (size_t)e * h->N, row);
+        if (ssq_sum) ssq_sum[i] = hssq[e];
+        if (status) status[i] = hst[e];
     }
-    KS_HIP(hipStreamSynchronize(h->stream));
     return KS_OK;
 }
 

@@ -12,6 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "model-based-pde-control_amd"))
 import kspde  # noqa: E402
+if os.environ.get("KSPDE_LIB"):      # A/B of library builds
+    kspde.LIB_PATH = os.path.abspath(os.environ["KSPDE_LIB"])
 from bench import forcing_matrix  # noqa: E402
 
 out = {}
