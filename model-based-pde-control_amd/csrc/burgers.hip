@@ -68,8 +68,29 @@ __device__ __forceinline__ void window(const float (&v)[P], float (&w)[P + 4]) {
     }
 }
 
+// Two points per instruction: gfx950 has packed fp32 VALU ops (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32, IEEE per
+// half, so the results are bit-identical to the scalar form), and this kernel is VALU-issue bound.  The stencil is
+// written on <2 x float> values whose halves are neighbouring points; the compiler pairs the registers.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 template <int P>
 __device__ __forceinline__ void residual(const float (&w)[P + 4], const float (&phi)[P], const Args& a, float (&r)[P]) {
+    if constexpr (P >= 2) {
+        const f32x2 hid = {a.half_inv_dx, a.half_inv_dx}, l0 = {a.l0, a.l0}, l1 = {a.l1, a.l1}, l2 = {a.l2, a.l2};
+#pragma unroll
+        for (int j = 0; j < P; j += 2) {
+            const f32x2 wm2 = {w[j], w[j + 1]}, wm1 = {w[j + 1], w[j + 2]}, w0 = {w[j + 2], w[j + 3]},
+                        wp1 = {w[j + 3], w[j + 4]}, wp2 = {w[j + 4], w[j + 5]}, ph = {phi[j], phi[j + 1]};
+            const f32x2 grad = (wp1 - wm1) * hid;
+            f32x2 lap = __builtin_elementwise_fma(l0, w0, ph);
+            lap = __builtin_elementwise_fma(l1, wm1 + wp1, lap);
+            lap = __builtin_elementwise_fma(l2, wm2 + wp2, lap);
+            const f32x2 rr = __builtin_elementwise_fma(-w0, grad, lap);
+            r[j] = rr[0];
+            r[j + 1] = rr[1];
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < P; ++j) {
         const float grad = (w[j + 3] - w[j + 1]) * a.half_inv_dx;
