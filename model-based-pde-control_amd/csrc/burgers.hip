@@ -101,6 +101,30 @@ __device__ __forceinline__ void residual(const float (&w)[P + 4], const float (&
     }
 }
 
+// Pair-native form of one residual evaluation for P >= 4 (P even): the state is held as P/2 <2 x float> pairs of
+// neighbouring points.  E[k] are the aligned pairs of the window (E[0] / E[P/2 + 1] the halo pairs from the neighbouring
+// lanes), O[k] = (E[k].hi, E[k+1].lo) the pairs at odd offsets -- ONE v_pk_mov_b32 each instead of two v_mov_b32.
+template <int H>   // H = P / 2 pairs per lane
+__device__ __forceinline__ void residual_pairs(const f32x2 (&U)[H], const f32x2 (&PH)[H], const Args& a, f32x2 (&R)[H]) {
+    f32x2 E[H + 2], O[H + 1];
+#pragma unroll
+    for (int k = 0; k < H; ++k) E[k + 1] = U[k];
+    E[0] = f32x2{from_lower(U[H - 1][0]), from_lower(U[H - 1][1])};
+    E[H + 1] = f32x2{from_upper(U[0][0]), from_upper(U[0][1])};
+#pragma unroll
+    for (int k = 0; k <= H; ++k) O[k] = __builtin_shufflevector(E[k], E[k + 1], 1, 2);
+    const f32x2 hid = {a.half_inv_dx, a.half_inv_dx}, l0 = {a.l0, a.l0}, l1 = {a.l1, a.l1}, l2 = {a.l2, a.l2};
+#pragma unroll
+    for (int k = 0; k < H; ++k) {
+        // points 2k, 2k + 1: centre E[k+1], +-2 E[k] / E[k+2], -1 O[k], +1 O[k+1]
+        const f32x2 grad = (O[k + 1] - O[k]) * hid;
+        f32x2 lap = __builtin_elementwise_fma(l0, E[k + 1], PH[k]);
+        lap = __builtin_elementwise_fma(l1, O[k] + O[k + 1], lap);
+        lap = __builtin_elementwise_fma(l2, E[k] + E[k + 2], lap);
+        R[k] = __builtin_elementwise_fma(-E[k + 1], grad, lap);
+    }
+}
+
 template <int P>
 __global__ void __launch_bounds__(256) bg_step_kernel(const Args a) {
     const int lane = threadIdx.x & 63;
@@ -127,6 +151,37 @@ __global__ void __launch_bounds__(256) bg_step_kernel(const Args a) {
     }
 
     double racc = 0.0;
+    if constexpr (P >= 4) {
+        constexpr int H = P / 2;
+        f32x2 U[H], PH[H];
+#pragma unroll
+        for (int k = 0; k < H; ++k) {
+            U[k] = f32x2{u[2 * k], u[2 * k + 1]};
+            PH[k] = f32x2{phi[2 * k], phi[2 * k + 1]};
+        }
+        const f32x2 hdt2 = {a.hdt, a.hdt}, dt2 = {a.dt, a.dt};
+        for (long s = 0; s < a.n_substeps; ++s) {
+            float q = 0.0f;
+#pragma unroll
+            for (int k = 0; k < H; ++k) {            // same order as the scalar form: u[0], u[1], ...
+                q = fmaf(U[k][0], U[k][0], q);
+                q = fmaf(U[k][1], U[k][1], q);
+            }
+            racc += (double)q;
+            f32x2 R[H], UT[H];
+            residual_pairs<H>(U, PH, a, R);
+#pragma unroll
+            for (int k = 0; k < H; ++k) UT[k] = __builtin_elementwise_fma(hdt2, R[k], U[k]);
+            residual_pairs<H>(UT, PH, a, R);
+#pragma unroll
+            for (int k = 0; k < H; ++k) U[k] = __builtin_elementwise_fma(dt2, R[k], U[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < H; ++k) {
+            u[2 * k] = U[k][0];
+            u[2 * k + 1] = U[k][1];
+        }
+    } else
     for (long s = 0; s < a.n_substeps; ++s) {
         float w[P + 4], r[P], ut[P];
         float q = 0.0f;
