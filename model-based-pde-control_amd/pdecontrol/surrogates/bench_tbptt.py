@@ -87,7 +87,9 @@ def time_graphed(device, batch, steps, warmup):
     torch.cuda.synchronize(device)
     dt = (time.perf_counter() - t0) / steps
     return {"value": batch[0].shape[0] / dt, "ms_per_step": dt * 1e3, "steps": steps,
-            "loss_after_training": float(graphed.result["loss"])}
+            "loss_after_training": float(graphed.result["loss"]),
+            "schedule_kept": "pipelined" if graphed.used_pipelined else "combined",
+            "schedule_autotune_ms": getattr(graphed, "schedule_times_ms", None)}
 
 
 def time_lightning_graphed(device, batch, steps, warmup):
@@ -195,9 +197,10 @@ def run_size(device, N, steps, warmup, B=64, with_plain=True, with_ensemble=True
     ms = res["hip_graph_fused"]["ms_per_step"]
     bytes_model = _hbm_model_bytes(B, 20, N)
     res["value"] = res["hip_graph_fused"]["value"]
-    res["hip_graph_fused"]["schedule"] = ("chunks pipelined: chunk 0's loss rows + backward on a side branch beside chunk 1's "
-                                          "forward (hipops.fused_tbptt_train); PDECONTROL_PIPELINED=0 for every chunk's backward "
-                                          "in the same launches")
+    res["hip_graph_fused"]["schedule"] = ("pipelined = chunk 0's loss rows + backward on a side branch beside chunk 1's forward "
+                                          "(hipops.fused_tbptt_train), combined = every chunk's backward in the same launches; both "
+                                          "are captured and timed once per batch shape, the faster one is kept (which hardware "
+                                          "queue the graph's second stream gets is the runtime's choice)")
     res["roofline"] = {"bound": "latency (dependent layer phases, one workgroup per sequence)", "kernels_per_step": 29,
                        "reference_torch_ops_per_step": "~4 000", "hbm_model_bytes_per_step": bytes_model,
                        "hbm_model_gbs": bytes_model / (ms * 1e-3) / 1e9, "hbm_frac_of_8TBs": bytes_model / (ms * 1e-3) / 8e12}

@@ -118,8 +118,17 @@ class GraphedTBPTTStep:
         capture=False prepares everything (static buffers, warmed-up kernels, optimizer state) but leaves
         the capture to the caller (EnsembleTBPTTStep records several members into one graph)."""
         self.module = module
-        # pipelined: chunk c's backward beside chunk c+1's forward (hipops.fused_tbptt_train); PDECONTROL_PIPELINED=0 opts out
-        self.pipelined = (os.environ.get("PDECONTROL_PIPELINED", "1") != "0") if pipelined is None else bool(pipelined)
+        # pipelined: chunk c's backward beside chunk c+1's forward (hipops.fused_tbptt_train).  True / False force one schedule;
+        # None (default, PDECONTROL_PIPELINED=auto) captures both and keeps the faster one: the pipelined graph needs its two
+        # node lists on two different hardware queues, and which queue ROCm gives the graph's second stream depends on how
+        # many streams the process has created (4 hardware queues): on an unlucky mapping the branches serialise and the
+        # combined schedule wins.  PDECONTROL_PIPELINED=0 / 1 force it from the environment.
+        env = os.environ.get("PDECONTROL_PIPELINED", "auto")
+        if pipelined is None and env in ("0", "1"):
+            pipelined = env == "1"
+        self.autotune = pipelined is None
+        self.pipelined = True if pipelined is None else bool(pipelined)
+        self.used_pipelined = False
         dev = next(module.surrogate.parameters()).device
         assert dev.type == "cuda", "HIP graphs need the module on a GPU"
         self.device = dev
@@ -175,6 +184,7 @@ class GraphedTBPTTStep:
         if self.pipelined and self._fused():
             # forward, loss, backward and gradient reduction hand-scheduled with the TBPTT chunks pipelined (no autograd)
             out = self.module._pipelined_training_step((self.states, self.actions))
+            self.used_pipelined = out is not None
             if out is not None:
                 return _detached(out)
         out = self.module._eager_training_step((self.states, self.actions), 0)
@@ -212,6 +222,48 @@ class GraphedTBPTTStep:
         return _LendAdam(self)
 
     def _capture(self):
+        self._capture_main()
+        if self.autotune and self.used_pipelined:
+            t_pipe = self._time_replays()
+            keep = (self.g_main, self.result, self.logged)
+            self.pipelined = False
+            self._capture_main()
+            t_comb = self._time_replays()
+            self.schedule_times_ms = {"pipelined": t_pipe, "combined": t_comb}
+            if t_pipe <= t_comb:
+                self.g_main, self.result, self.logged = keep
+                self.pipelined = self.used_pipelined = True
+        if self.distributed:
+            self.g_opt = torch.cuda.CUDAGraph()
+            capture_graph(self.g_opt, self.shared.opt.step, self.stream)
+
+    def _time_replays(self, warm=3, reps=10):
+        """Mean replay time of ``g_main`` in ms, with the parameters and the Adam state put back afterwards."""
+        packs = getattr(self.module.surrogate, "_fused_packs", None)
+        tensors = list(self.shared._params)
+        if packs is not None:
+            for pack in packs.packs:
+                if pack._adam_state is not None:
+                    tensors.extend(pack._adam_state)
+        if self.shared.opt is not None:
+            for st in self.shared.opt.state.values():
+                tensors.extend(t for t in st.values() if isinstance(t, torch.Tensor))
+        snap = [t.detach().clone() for t in tensors]
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(warm):
+            self.g_main.replay()
+        start.record()
+        for _ in range(reps):
+            self.g_main.replay()
+        end.record()
+        torch.cuda.synchronize(self.device)
+        with torch.no_grad():
+            for t, sv in zip(tensors, snap):
+                t.copy_(sv)
+        torch.cuda.synchronize(self.device)
+        return start.elapsed_time(end) / reps
+
+    def _capture_main(self):
         self.g_main = torch.cuda.CUDAGraph()
 
         def main():
@@ -224,9 +276,6 @@ class GraphedTBPTTStep:
         self.result = capture_graph(self.g_main, main, self.stream)
         # training_step's logged metrics of THIS captured step (static tensors, refreshed by every replay)
         self.logged = dict(self.module.__dict__.pop("_graph_logged", {}))
-        if self.distributed:
-            self.g_opt = torch.cuda.CUDAGraph()
-            capture_graph(self.g_opt, self.shared.opt.step, self.stream)
 
     def set_lr(self, lr):
         self.shared.set_lr(lr, getattr(self.module.surrogate, "_fused_packs", None))

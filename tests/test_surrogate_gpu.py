@@ -180,6 +180,27 @@ def test_split_graph_step_is_what_automatic_optimization_drives():
     assert any(not torch.equal(p, ref[n]) for n, p in split.surrogate.named_parameters())
 
 
+def test_schedule_autotune_leaves_parameters_and_adam_state_untouched():
+    """GraphedTBPTTStep(pipelined=None) captures the pipelined and the combined schedule, times both and keeps the faster
+    one; the timing replays must not train: parameters, Adam moments and the step counter are put back."""
+    from pdecontrol.surrogates.bench_tbptt import build_module, synthetic_batch
+    from pdecontrol.surrogates.graph_step import GraphedTBPTTStep
+    dev = torch.device("cuda", 0)
+    batch = synthetic_batch(B=8, device=dev)
+    tuned, forced = build_module(dev), build_module(dev)
+    before = torch.cat([p.detach().reshape(-1) for p in tuned.surrogate.parameters()]).clone()
+    g_auto = GraphedTBPTTStep(tuned, tuple(batch[0].shape))
+    g_pipe = GraphedTBPTTStep(forced, tuple(batch[0].shape), pipelined=True)
+    assert g_auto.autotune and set(g_auto.schedule_times_ms) == {"pipelined", "combined"} and not g_pipe.autotune
+    after = torch.cat([p.detach().reshape(-1) for p in tuned.surrogate.parameters()])
+    assert torch.equal(before, after)
+    assert tuned.surrogate._fused_packs.adam_step_count() == 0
+    la = [float(g_auto.step(*batch)["loss"]) for _ in range(3)]
+    lp = [float(g_pipe.step(*batch)["loss"]) for _ in range(3)]
+    np.testing.assert_allclose(la, lp, rtol=2e-5)
+    assert tuned.surrogate._fused_packs.adam_step_count() == 3
+
+
 def test_refitted_delta_statistics_invalidate_the_captured_graphs():
     """The controller re-fits the delta Normalize between training rounds (mbrl.py:597-602) on the object the surrogate's
     dscaling and the module's undscaling share; captured launches carry (mean, std) by value, so every graph cache must
