@@ -2,7 +2,11 @@
 """bench.py -- headline benchmark of the MI355X-native KS hot path (+ surrogate TBPTT step).
 
 Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N > 1 it is launched
-under torch.distributed.run with one rank per GPU.  Rank 0 prints ONE JSON line.
+under torch.distributed.run with one rank per GPU.  Rank 0 prints ONE JSON line.  Started DIRECTLY with
+``--gpus N`` (N > 1, no WORLD_SIZE in the environment) the GPU-free parent starts the N ranks itself as fresh child
+processes of ``python -m torch.distributed.run`` (never an exec, nothing has touched the GPU yet) and relays rank 0's
+line; the N > 1 line carries ``ranks`` = what the process group itself reports (backend, world size, one gathered
+record per rank with its device and uuid, a checked all-reduce, every rank's own step time).
 
 What one "step" is: one ``env.step`` of the whole batch = ONE launch of the fused HIP stepper that
 advances every env by cfg_steps = 250 RK4 sub-steps (pdegym/kuramoto/kuramoto.py:78-98 of the
@@ -32,6 +36,7 @@ import argparse
 import hashlib
 import json
 import os
+import socket
 import subprocess
 import sys
 import time
@@ -336,6 +341,62 @@ def measured_hbm_copy_gbs(dev, mib=1024, reps=10):
     torch.cuda.synchronize(dev)
     return 2.0 * a.numel() * 4 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
+# ---------------------------------------------------------------------------------------------------------
+# N > 1: rank processes and what they report about themselves
+# ---------------------------------------------------------------------------------------------------------
+def spawn_ranks(n, argv):
+    """``python bench.py --gpus N`` started directly: start N fresh rank processes (torch.distributed.run, one per GPU,
+    rendezvous on 127.0.0.1) from this process, which has not touched the GPU, and relay rank 0's JSON line.  On a box
+    with fewer GPUs than ranks the ranks share devices over gloo -- a rehearsal of the code path, flagged as such in the
+    line (``ranks.rehearsal``), never a scaling number.  Returns the launcher's exit code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n)))
+    if "BENCH_DIST_BACKEND" not in env and torch.cuda.device_count() < n:   # device_count() does not initialise the GPU
+        env["BENCH_DIST_BACKEND"] = "gloo"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for raw in proc.stdout:             # rank 0 prints exactly one JSON line; anything else is passed to stderr
+        txt = raw.strip()
+        if txt.startswith("{") and '"metric"' in txt:
+            line = txt
+        elif txt:
+            print(txt, file=sys.stderr)
+    rc = proc.wait()
+    if line is not None:
+        print(line)
+    elif rc == 0:
+        rc = 1
+    return rc
+
+
+def rank_evidence(dist, backend, dev, rank, local_rank, world, elapsed, kernel_ms, K):
+    """What the process group itself says about the ranks: one gathered record per rank, a checked all-reduce on the
+    backend's own device type, every rank's step time (a straggler shows).  Every rank calls this."""
+    props = torch.cuda.get_device_properties(dev)
+    me = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.current_device(),
+          "uuid": str(getattr(props, "uuid", "")), "pci_bus_id": getattr(props, "pci_bus_id", None), "name": props.name,
+          "gcn_arch": getattr(props, "gcnArchName", None), "pid": os.getpid(), "host": socket.gethostname(),
+          "ms_per_step": elapsed / K * 1e3, "kernel_ms": kernel_ms}
+    gathered = [None] * world
+    dist.all_gather_object(gathered, me)
+    cdev = dev if backend == "nccl" else "cpu"
+    x = torch.tensor([rank + 1.0], dtype=torch.float64, device=cdev)
+    dist.all_reduce(x, op=dist.ReduceOp.SUM)
+    devices = {(r["host"], r["uuid"] or r["device"]) for r in gathered}
+    return {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+            "collective": "RCCL (torch 'nccl' backend on ROCm)" if backend == "nccl" else backend,
+            "all_reduce_check": {"sum_of_rank_plus_1": float(x.item()), "expected": world * (world + 1) / 2.0,
+                                 "ok": float(x.item()) == world * (world + 1) / 2.0, "on": str(cdev)},
+            "distinct_devices": len(devices), "rehearsal": len(devices) < world,
+            "ms_per_step": [r["ms_per_step"] for r in gathered], "kernel_ms": [r["kernel_ms"] for r in gathered],
+            "per_rank": [{k: v for k, v in r.items() if k not in ("ms_per_step", "kernel_ms")} for r in gathered]}
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -355,8 +416,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     n_gpus = world if world > 1 else args.gpus
-    if world == 1 and args.gpus != 1:
-        sys.exit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py ...")
+    if world == 1 and args.gpus > 1:
+        # started directly: this process stays GPU-free and starts the ranks itself
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     E, N, L, cfg_idx = WORKLOADS[args.workload]
     K, W = args.steps, args.warmup
 
@@ -397,10 +459,12 @@ def main():
 
     run = KSRun(kspde, args.workload, local_rank, dev, rank, K + W, args.mode, args.variant)
     elapsed, kernel_ms = run.timed(K, W, barrier)
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    ranks = None
     if dist is not None:
+        ranks = rank_evidence(dist, backend, dev, rank, local_rank, world, elapsed, kernel_ms, K)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+        elapsed = float(t.item())
 
     lay = run.stepper.layout()
     total_substeps = n_gpus * E * CFG_STEPS * K
@@ -426,6 +490,8 @@ def main():
         },
         "roofline": roofline_of(args.workload, E, N, kernel_ms, lay),
     }
+    if ranks is not None:
+        out["ranks"] = ranks
     if rank == 0 and n_gpus == 1:
         try:
             out["roofline"]["hbm_copy_measured"] = {"value": measured_hbm_copy_gbs(dev), "unit": "GB/s",
@@ -475,11 +541,16 @@ def main():
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         td = torch.tensor([0.0 if ddp is None else ddp[0]], dtype=torch.float64, device=cdev)
         dist.all_reduce(td, op=dist.ReduceOp.MAX)
+        # "in sync" is every rank's comparison with rank 0's parameters: rank 0's own is trivially true
+        sync = torch.tensor([1.0 if (ddp is not None and ddp[1]) else 0.0], dtype=torch.float64, device=cdev)
+        dist.all_reduce(sync, op=dist.ReduceOp.MIN)
         if float(ok.item()) == 1.0:
-            _dt, in_sync, loss_ddp, nbytes = ddp
+            _dt, _, loss_ddp, nbytes = ddp
+            in_sync = float(sync.item()) == 1.0
             out["tbptt"] = {"unit": "seqs/s", "value": n_gpus * 64 / float(td.item()), "ms_per_step": float(td.item()) * 1e3,
                             "scaling": "weak", "B_per_rank": 64, "N": 256, "ranks_in_sync": in_sync, "loss": loss_ddp,
                             "exchange": f"one all-reduce of the flat {nbytes}-byte fp32 gradient bucket per step",
+                            "backend": dist.get_backend(),
                             "path": "fused HIP kernels, fwd/bwd hipGraph (chunks pipelined) + all-reduce + Adam hipGraph"}
         else:
             out["tbptt"] = {"error": err or "the data-parallel step failed on another rank"}

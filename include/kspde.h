@@ -16,7 +16,10 @@
  *     distinct host threads
  *   - "host" pointers are ordinary host memory owned by the caller; the *_device variants
  *     take device pointers, enqueue on the handle's stream and do NOT synchronise
- *   - there is NO CPU implementation behind this ABI: device must name a HIP device
+ *   - device >= 0 names a HIP device; nothing ever falls back to the CPU.  device = -1 is an EXPLICIT request for
+ *     the CPU twin (csrc/ks_cpu.cpp: the same arithmetic on host memory, same entry points; BASELINE configs[0],
+ *     SURVEY 8(b) b4 / 8(d) baseline (B)); on such a handle the *_device entries take host pointers and run
+ *     synchronously, ks_set_stream / a non-auto ks_set_variant return KS_ERR_UNSUPPORTED
  *
  * State layout in HBM: u is fp64, row-major [num_envs, N] (one env = one contiguous row of
  * N doubles); phi / obs are fp32 [num_envs, N]; actions fp32 [num_envs, n_act];
@@ -65,7 +68,8 @@ typedef enum ks_variant {
 /* ---- lifetime -------------------------------------------------------------------------- */
 
 /* Replaces: KuramotoSivashinskyEnv.__init__ (pdegym/kuramoto/kuramoto.py:29-57) for a batch of
- * num_envs independent environments: grid size N, domain length L (dx = L/N), RK4 step dt. */
+ * num_envs independent environments: grid size N, domain length L (dx = L/N), RK4 step dt.
+ * device: HIP device ordinal, or -1 for the CPU twin. */
 int ks_create(int device, int num_envs, int N, double L, double dt, ks_handle** out);
 int ks_destroy(ks_handle* h);
 
@@ -121,6 +125,19 @@ int ks_step_actions(ks_handle* h, const float* actions_host, long n_substeps, fl
  * kuramoto.py:103-109: Tsteps * cfg_steps sub-steps).  Outputs are indexed by position i. */
 int ks_step_rows(ks_handle* h, const int* env_ids_host, int n, long n_substeps, float* obs_f32,
                  double* ssq_sum, int* status);
+
+/* Split form of the host-boundary step, for ONE host thread driving several handles (one per GPU; replaces the
+ * reference's one-subprocess-per-env AsyncVectorEnv.step_async / step_wait, pdecontrol/mbrl/mbrl.py:81-86):
+ * ks_step_begin stages its inputs through pinned memory, enqueues the launch and the copy of the outputs into the
+ * handle's pinned mirror, and returns WITHOUT waiting; ks_step_end waits for that step and hands the results over.
+ * Call begin on every handle first, then end on every handle: all devices run concurrently.
+ *   actions_host  fp32 [num_envs, n_act] or NULL (phi = 0)
+ *   env_ids_host  int [n_rows] subset (outputs then in list order, as ks_step_rows) or NULL = all envs
+ *   want_obs      0: ks_step_end may only be given obs_f32 = NULL
+ * Between begin and end the handle accepts no other call that touches the stream (KS_ERR_INVALID). */
+int ks_step_begin(ks_handle* h, const float* actions_host, const int* env_ids_host, int n_rows, long n_substeps,
+                  int want_obs);
+int ks_step_end(ks_handle* h, float* obs_f32, double* ssq_sum, int* status);
 
 /* Asynchronous, device-resident form: every pointer is a DEVICE pointer (or NULL), the launch is
  * enqueued on the handle's stream and the call returns immediately.  Exactly one of d_phi /

@@ -2,7 +2,10 @@
 
 This is the only way Python reaches the HIP stepper.  There is no fallback: if the shared
 library has not been built (``python __graft_entry__.py`` / ``make -C csrc``) or no HIP device is
-visible, construction fails loudly.
+visible, construction fails loudly.  ``device=-1`` (or ``"cpu"``) is an explicit request for the library's CPU twin
+(csrc/ks_cpu.cpp, same entry points): BASELINE configs[0] on a GPU-less host.
+
+``KSPDE_LIB`` overrides the library path (the sanitizer build: ``make -C csrc asan``).
 """
 import ctypes
 import os
@@ -37,6 +40,8 @@ SYMBOLS = (
     ("ks_step", _c.c_int, [_H, _c.c_void_p, _c.c_long, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
     ("ks_step_actions", _c.c_int, [_H, _c.c_void_p, _c.c_long, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
     ("ks_step_rows", _c.c_int, [_H, _c.c_void_p, _c.c_int, _c.c_long, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
+    ("ks_step_begin", _c.c_int, [_H, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_long, _c.c_int]),
+    ("ks_step_end", _c.c_int, [_H, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
     ("ks_step_device", _c.c_int, [_H, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_long, _c.c_void_p,
                                   _c.c_void_p, _c.c_void_p]),
     ("ks_sync", _c.c_int, [_H]),
@@ -62,7 +67,7 @@ def load():
         # FIRST so that libkspde's NEEDED libamdhip64.so.7 binds to that already-loaded copy: two HIP
         # runtimes in one process cannot both own the GPU ("No HIP GPUs are available").
         import torch  # noqa: F401
-        path = os.path.abspath(LIB_PATH)
+        path = os.path.abspath(os.environ.get("KSPDE_LIB") or LIB_PATH)
         if not os.path.exists(path):
             raise KSError(
                 f"{path} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; "
@@ -92,6 +97,8 @@ class KSStepper:
     def __init__(self, num_envs, N=64, L=22.0, dt=1e-3, device=0, mode="fast", variant="auto"):
         self._lib = load()
         self._h = _H()
+        if isinstance(device, str):
+            device = -1 if device == "cpu" else int(device)
         self.num_envs, self.N, self.L, self.dt, self.device = int(num_envs), int(N), float(L), float(dt), int(device)
         self.dx = self.L / self.N
         _check(self._lib.ks_create(self.device, self.num_envs, self.N, self.L, self.dt, ctypes.byref(self._h)))
@@ -184,6 +191,29 @@ class KSStepper:
         ids = np.ascontiguousarray(env_ids, dtype=np.int32)
         obs, ssq, st = self._outs(len(ids), want_obs)
         _check(self._lib.ks_step_rows(self._h, _ptr(ids), len(ids), int(n_substeps), _ptr(obs), _ptr(ssq), _ptr(st)))
+        return obs, ssq, st
+
+    def step_begin(self, actions=None, env_ids=None, n_substeps=250, want_obs=True):
+        """Enqueue a host-boundary step and return without waiting (``step_end`` collects it): begin on every handle of
+        a multi-device env first, then end on each."""
+        a = None
+        if actions is not None:
+            a = np.ascontiguousarray(np.asarray(actions, dtype=np.float32).reshape(self.num_envs, -1))
+            assert a.shape[1] == self.n_act, (a.shape, self.n_act)
+        ids = None if env_ids is None else np.ascontiguousarray(env_ids, dtype=np.int32)
+        self._pending_rows = self.num_envs if ids is None else len(ids)
+        self._pending_obs = bool(want_obs)
+        _check(self._lib.ks_step_begin(self._h, _ptr(a), _ptr(ids), 0 if ids is None else len(ids), int(n_substeps),
+                                       int(bool(want_obs))))
+
+    def step_end(self, out=None):
+        """Wait for the step ``step_begin`` enqueued.  ``out`` = (obs, ssq, status) arrays (or slices of larger
+        C-contiguous ones) to fill; allocated when None."""
+        n = self._pending_rows
+        obs, ssq, st = out if out is not None else self._outs(n, self._pending_obs)
+        for a_, shape in ((obs, (n, self.N)), (ssq, (n,)), (st, (n,))):
+            assert a_ is None or (a_.shape == shape and a_.flags["C_CONTIGUOUS"]), (None if a_ is None else a_.shape, shape)
+        _check(self._lib.ks_step_end(self._h, _ptr(obs), _ptr(ssq), _ptr(st)))
         return obs, ssq, st
 
     def step_device(self, d_phi=0, d_actions=0, d_env_ids=0, n_rows=0, n_substeps=250, d_obs=0, d_ssq=0,
