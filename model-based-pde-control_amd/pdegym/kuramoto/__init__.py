@@ -4,6 +4,8 @@ Mirror of the reference's ``pdegym/kuramoto/__init__.py`` (``make`` :8-12, ``mak
 registration of ``KuramotoSivashinskyEnv-v0`` / ``KuramotoSivashinskyEnvSB3-v0`` :26-37), plus
 ``make_vec``: the HBM-resident batched vector env that replaces ``gym.vector.make(id, num_envs)``.
 """
+import os
+
 from pdegym._gym import gym
 from pdegym.kuramoto.kuramoto import KuramotoSivashinskyEnv
 from pdegym.kuramoto.batched import KSBatchedVecEnv, shard_envs
@@ -14,14 +16,23 @@ ENV_ID = "KuramotoSivashinskyEnv-v0"
 ENV_ID_SB3 = "KuramotoSivashinskyEnvSB3-v0"
 
 
+def _with_device(config):
+    """``PDEGYM_DEVICE`` (``cpu`` or a HIP ordinal) chooses the stepper's device for envs whose config does not: the
+    route by which an unmodified caller runs BASELINE configs[0] on the library's CPU twin."""
+    dev = os.environ.get("PDEGYM_DEVICE", "")
+    if dev and "device" not in config:
+        config = dict(config, device=-1 if dev.lower() == "cpu" else int(dev))
+    return config
+
+
 def make(config={}, new_step_api=True):
-    env = KuramotoSivashinskyEnv(**config)
+    env = KuramotoSivashinskyEnv(**_with_device(config))
     return TimeLimit(env, env.unwrapped.max_episode_steps, new_step_api=new_step_api)
 
 
 def make_sb3(config={}):
     from pdegym.common.wrappers import UnFlattenActionWrapper, UnFlattenObsWrapper
-    env = KuramotoSivashinskyEnv(**config)
+    env = KuramotoSivashinskyEnv(**_with_device(config))
     env = UnFlattenActionWrapper(UnFlattenObsWrapper(env))
     rescale = getattr(gym.wrappers, "RescaleAction", None)
     if rescale is not None:

@@ -4,8 +4,8 @@ Drop-in for the reference's ``pdegym/kuramoto/kuramoto.py`` (class name, module 
 keywords and defaults :29-41, attributes, ``step`` :78-98, ``reset`` :100-116, ``rhs`` :118-129,
 ``time`` / ``scenario`` :131-150).  Nothing numerical happens in this file: the RK4 / finite
 difference work is one launch of ``libkspde.so`` per ``step`` (all ``cfg_steps`` sub-steps fused)
-and one launch per ``reset`` (the whole 200 000 sub-step burn-in).  There is no CPU
-implementation behind it; without the HIP library or a GPU, stepping raises.
+and one launch per ``reset`` (the whole 200 000 sub-step burn-in).  Without the HIP library or a GPU, stepping
+raises; ``device=-1`` (``"cpu"``) asks for the library's CPU twin explicitly (BASELINE configs[0]).
 
 Differences from the reference that a caller can observe:
   * ``env.u`` is a property backed by device memory (reads copy D2H, assignment copies H2D).
@@ -73,6 +73,8 @@ class KuramotoSivashinskyEnv(gym.Env):
         self.action_space = gym.spaces.Box(-1.0, 1.0, shape=(1, len(self.Xi)), dtype=np.float32)
         self.observation_space = gym.spaces.Box(-np.inf, np.inf, shape=(1, self.N), dtype=np.float32)
 
+        if isinstance(device, str):
+            device = -1 if device.lower() == "cpu" else int(device)
         self.device, self.step_mode, self.reset_mode, self.variant = device, step_mode, reset_mode, variant
         self._stepper_cls = _stepper_cls
         self._stepper = None  # created lazily: constructing the env must not touch the GPU
