@@ -83,6 +83,14 @@ def host_cores():
     return n
 
 
+def default_reset_mode():
+    try:
+        from pdegym.kuramoto.batched import DEFAULT_RESET_MODE
+        return DEFAULT_RESET_MODE()
+    except Exception:
+        return None
+
+
 def kernel_source_sha():
     """Identity of the KS kernel sources: profile-derived numbers (PMC traffic, SQ counters) are only quoted while the
     kernel they were measured on is the kernel that runs."""
@@ -214,7 +222,7 @@ class KSRun:
     def __init__(self, kspde, name, local_rank, dev, rank, steps, mode, variant="auto"):
         self.E, self.N, self.L, self.cfg = WORKLOADS[name]
         E, N, L = self.E, self.N, self.L
-        self.name, self.dev = name, dev
+        self.name, self.dev, self.mode = name, dev, mode
         self.stepper = kspde.KSStepper(E, N, L, DT, device=local_rank, mode=mode, variant=variant)
         self.stream = torch.cuda.Stream(device=dev)
         self.stepper.set_stream(self.stream.cuda_stream)
@@ -253,6 +261,65 @@ class KSRun:
         torch.cuda.synchronize(self.dev)
         assert int(self.st_acc.sum()) == 0, "non-finite state during the benchmark"
         return elapsed, float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+
+def end_to_end_leg(run, K=20, W=3):
+    """SURVEY 8(d) "end-to-end" figure: the same step through the HOST-buffer entry (ks_step_actions: actions [E, 4] fp32
+    from pageable host memory, fp32 observations + reward sums + status back into host arrays, one synchronisation) --
+    PCIe inclusive, what gym's step() costs a host-side controller.  Never ``value``."""
+    st, E, N = run.stepper, run.E, run.N
+    acts = np.random.RandomState(7).uniform(-1, 1, (K + W, E, 4)).astype(np.float32)
+    torch.cuda.synchronize(run.dev)
+    for i in range(W):
+        st.step_actions(acts[i], CFG_STEPS)
+    t0 = time.perf_counter()
+    for i in range(K):
+        _, _, status = st.step_actions(acts[W + i], CFG_STEPS)
+    dt = (time.perf_counter() - t0) / K
+    assert not status.any()
+    gbs = 20.0 * N * E * CFG_STEPS / dt / 1e9
+    return {"value": E * CFG_STEPS / dt, "unit": "sub-steps/s", "ms_per_step": dt * 1e3, "steps": K,
+            "hbm_model_frac": gbs / HBM_PEAK_GBS,
+            "host_bytes_per_step": {"h2d_actions": E * 16, "d2h_obs_f32": E * N * 4, "d2h_reward_status": E * 12},
+            "what": "ks_step_actions: host actions in, host obs / reward sums / status out, synchronous (PCIe inclusive)"}
+
+
+def episode_leg(run, reset_mode, ring=8):
+    """What a real run of the reference's loop sees per episode (pdegym/kuramoto/kuramoto.py:100-116: the reset burn-in is
+    800 step-equivalents, two thirds of all sub-steps): max_episode_steps = 400 steps of every env in the step arithmetic
+    (fast), then the autoreset all envs take together -- fresh initial conditions uploaded + ONE launch of the 200 000
+    sub-step burn-in in ``reset_mode``.  Device resident like ``value`` (drawing the ICs with NumPy on the host is
+    outside the timed region and reported beside it)."""
+    st, E, N, dev = run.stepper, run.E, run.N, run.dev
+    steps, burn = 400, 200000
+    t0 = time.perf_counter()
+    u0 = np.stack([np.random.RandomState(4321 + e).uniform(-0.4, 0.4, N) for e in range(E)])
+    ic_ms = (time.perf_counter() - t0) * 1e3
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    with torch.cuda.stream(run.stream):
+        for i in range(steps):
+            run.one_step(i % ring)
+        t_steps = None
+        st.set_state(u0)                       # synchronises: the 400 steps are done here
+        t_steps = time.perf_counter() - t0
+        st.set_mode(reset_mode)
+        e0.record(run.stream)
+        st.step_device(n_substeps=burn, d_obs=run.d_obs.data_ptr(), d_ssq=run.d_ssq.data_ptr(), d_status=run.d_st.data_ptr())
+        e1.record(run.stream)
+        st.set_mode(run.mode)
+    torch.cuda.synchronize(dev)
+    total = time.perf_counter() - t0
+    assert int(run.d_st.sum()) == 0, "non-finite state after the burn-in"
+    burn_ms = e0.elapsed_time(e1)
+    sub = E * (steps * CFG_STEPS + burn)
+    frac = lambda substeps, seconds: 20.0 * N * substeps / seconds / 1e9 / HBM_PEAK_GBS
+    return {"value": sub / total, "unit": "sub-steps/s", "seconds_per_episode": total, "hbm_model_frac": frac(sub, total),
+            "steps": {"count": steps, "seconds": t_steps, "mode": run.mode},
+            "reset": {"mode": reset_mode, "sub_steps": burn, "kernel_ms": burn_ms,
+                      "hbm_model_frac": frac(E * burn, burn_ms * 1e-3), "ic_upload_included": True,
+                      "ic_draw_on_host_ms_not_included": ic_ms}}
 
 
 def burgers_fno_leg(dev, steps=30, warmup=5):
@@ -410,6 +477,7 @@ def main():
     ap.add_argument("--no-tbptt", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-burgers", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the end_to_end / episode_inclusive legs")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -500,6 +568,21 @@ def main():
             out["roofline"]["hbm_copy_measured"] = {"error": f"{type(exc).__name__}: {exc}"}
         if cpu_ks is not None:
             out["cpu_baseline"] = cpu_ks
+        if not args.no_extras:
+            # the two figures SURVEY 8(d) asks for next to ``value``: PCIe-inclusive, and with the reset burn-in
+            try:
+                out["end_to_end"] = end_to_end_leg(run)
+            except Exception as exc:
+                out["end_to_end"] = {"error": f"{type(exc).__name__}: {exc}"}
+            out["episode_inclusive"] = {
+                "what": "400 env steps + the autoreset of every env (fresh ICs + 200 000-sub-step burn-in, "
+                        "kuramoto.py:100-116), device resident; per reset arithmetic",
+                "default_reset_mode": default_reset_mode()}
+            for rm in ("fast", "exact"):
+                try:
+                    out["episode_inclusive"][rm + "_reset"] = episode_leg(run, rm)
+                except Exception as exc:
+                    out["episode_inclusive"][rm + "_reset"] = {"error": f"{type(exc).__name__}: {exc}"}
         if not args.no_secondary:
             # the other single-GPU BASELINE config in the same run -- not the headline value
             other = "c2" if args.workload == "c3" else "c3"

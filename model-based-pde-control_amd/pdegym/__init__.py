@@ -7,7 +7,8 @@ Importing the package registers the environments with gym, like the reference's
 Batched GPU vector envs: set ``PDEGYM_BATCHED=1`` (or call ``install_batched_vector_make()``) and
 ``gym.vector.make("KuramotoSivashinskyEnv-v0", num_envs=E)`` -- the call the reference's
 controller makes (pdecontrol/mbrl/mbrl.py:81-86) -- returns one ``KSBatchedVecEnv`` instead of E
-subprocess envs, so ``pdecontrol/mbrl/script.py`` needs no edit.
+subprocess envs, so ``pdecontrol/mbrl/script.py`` needs no edit.  With ``PDEGYM_DEVICES=all`` (or ``0,1,2,3``) the same
+call returns a ``KSShardedVecEnv``: the one controller process drives every listed GPU.
 """
 import os
 
@@ -16,8 +17,8 @@ import pdegym.burgers  # noqa: F401  (registers BurgersEnv-v0; loads no GPU libr
 import pdegym.kuramoto  # noqa: F401  (registers the env ids)
 
 
-def install_batched_vector_make(device=None):
-    """Route ``gym.vector.make`` for the KS env ids to the batched HIP vector env."""
+def install_batched_vector_make(device=None, devices=None):
+    """Route ``gym.vector.make`` for the KS env ids to the batched HIP vector env (``devices``: to the sharded one)."""
     from pdegym.kuramoto import ENV_ID, make_vec
     previous = getattr(gym.vector, "make", None)
     if getattr(previous, "_pdegym_batched", False):
@@ -25,8 +26,11 @@ def install_batched_vector_make(device=None):
 
     def vector_make(id, num_envs=1, asynchronous=True, wrappers=None, **kwargs):
         if id == ENV_ID:
-            dev = device if device is not None else int(os.environ.get("LOCAL_RANK", "0"))
             kwargs.pop("new_step_api", None)
+            devs = devices if devices is not None else (os.environ.get("PDEGYM_DEVICES") or None)
+            if devs is not None:
+                return make_vec(num_envs, config=kwargs.pop("config", {}), devices=devs, **kwargs)
+            dev = device if device is not None else int(os.environ.get("LOCAL_RANK", "0"))
             return make_vec(num_envs, config=kwargs.pop("config", {}), device=dev, **kwargs)
         if previous is None:
             raise KeyError(f"no vector factory for env {id!r}")

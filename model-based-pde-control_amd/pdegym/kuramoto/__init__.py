@@ -9,6 +9,7 @@ import os
 from pdegym._gym import gym
 from pdegym.kuramoto.kuramoto import KuramotoSivashinskyEnv
 from pdegym.kuramoto.batched import KSBatchedVecEnv, shard_envs
+from pdegym.kuramoto.sharded import KSShardedVecEnv, resolve_devices
 
 TimeLimit = gym.wrappers.TimeLimit
 
@@ -40,8 +41,11 @@ def make_sb3(config={}):
     return TimeLimit(env, env.unwrapped.max_episode_steps)
 
 
-def make_vec(num_envs, config={}, device=0, **kwargs):
-    """Batched replacement for ``gym.vector.make(ENV_ID, num_envs=...)``: one GPU batch."""
+def make_vec(num_envs, config={}, device=0, devices=None, **kwargs):
+    """Batched replacement for ``gym.vector.make(ENV_ID, num_envs=...)``: one GPU batch, or -- ``devices`` = a list of
+    ordinals / ``"all"`` -- contiguous env blocks on several GPUs behind one vector env (one controller process)."""
+    if devices is not None:
+        return KSShardedVecEnv(num_envs, config=config, devices=devices, **kwargs)
     return KSBatchedVecEnv(num_envs, config=config, device=device, **kwargs)
 
 

@@ -12,19 +12,23 @@ is kept:
   * autoreset: when an env truncates, ``infos["final_observation"][i]`` holds its last
     observation (``None`` elsewhere), ``infos["_final_observation"]`` is the mask, and the returned
     observation is the one after reset (fresh IC + 200 000 sub-step burn-in, run on the GPU for
-    just those envs).
+    just those envs; in ``reset_mode`` arithmetic -- "fast" by default, "exact" = the reference's
+    realisation bit for bit, see kuramoto.py).
   * seeding: ``reset(seed=s)`` seeds env i with ``s + i`` (gym's vector convention); the IC of env
     i is then exactly what the reference's ``reset(seed=s+i)`` draws.
 
 Multi-GPU: envs are independent, so a job shards them by rank with ``shard_envs`` and every rank
-builds its own KSBatchedVecEnv on its own GPU; no collective is involved.
+builds its own KSBatchedVecEnv on its own GPU; no collective is involved.  A SINGLE controller process (what
+pdecontrol/mbrl/script.py is) reaches several GPUs through ``KSShardedVecEnv`` (pdegym/kuramoto/sharded.py).
 """
 from typing import Optional, Sequence
 
 import numpy as np
 
 from pdegym._gym import gym
-from pdegym.kuramoto.kuramoto import KuramotoSivashinskyEnv
+from pdegym.kuramoto.kuramoto import KuramotoSivashinskyEnv, default_reset_mode
+
+DEFAULT_RESET_MODE = default_reset_mode
 
 
 def shard_envs(num_envs: int, rank: int, world_size: int):
@@ -36,8 +40,13 @@ def shard_envs(num_envs: int, rank: int, world_size: int):
 
 class KSBatchedVecEnv(gym.vector.VectorEnv):
     def __init__(self, num_envs: int, config: Optional[dict] = None, device: int = 0, step_mode: str = "fast",
-                 reset_mode: str = "exact", variant: str = "auto", burn_in: bool = True, _stepper_cls=None):
+                 reset_mode: Optional[str] = None, variant: str = "auto", burn_in: bool = True, _stepper_cls=None):
         config = dict(config or {})
+        # an env config may carry the stepper options too (that is how gym.make(id, config=...) passes them)
+        step_mode = config.pop("step_mode", step_mode)
+        reset_mode = config.pop("reset_mode", reset_mode) or default_reset_mode()
+        device = config.pop("device", device)
+        variant = config.pop("variant", variant)
         # a (never stepped) single env supplies spaces, forcing matrix, reward function, constants
         self.proto = KuramotoSivashinskyEnv(**config)
         p = self.proto
@@ -51,11 +60,15 @@ class KSBatchedVecEnv(gym.vector.VectorEnv):
         if _stepper_cls is None:
             import kspde  # fails loudly if libkspde.so is missing
             _stepper_cls = kspde.KSStepper
-        self.stepper = _stepper_cls(num_envs, self.N, self.L, self.dt, device=device, mode=step_mode, variant=variant)
-        self.stepper.set_forcing(p.forcing.forcing.numpy())
+        self._build_steppers(_stepper_cls, variant)
         self.timestep = np.zeros(num_envs, dtype=np.int64)
         self._rngs = [np.random.RandomState() for _ in range(num_envs)]
         self._actions = None
+
+    def _build_steppers(self, stepper_cls, variant):
+        self.stepper = stepper_cls(self.num_envs, self.N, self.L, self.dt, device=self.device, mode=self.step_mode,
+                                   variant=variant)
+        self.stepper.set_forcing(self.proto.forcing.forcing.numpy())
 
     # attributes the reference reads through ``env.unwrapped`` / ``get_attr``
     @property
@@ -118,6 +131,10 @@ class KSBatchedVecEnv(gym.vector.VectorEnv):
         assert self._actions is not None, "step_wait() without step_async()"
         obs, ssq, status = self.stepper.step_actions(self._actions, self.cfg_steps)
         self._actions = None
+        return self._finish_step(obs, ssq, status)
+
+    def _finish_step(self, obs, ssq, status):
+        """Rewards, episode bookkeeping and autoreset from the raw outputs of one step of every env."""
         self._raise_on(status)
         rewards = (-1.0) * (1 / self.N) * ssq / self.cfg_steps
         self.timestep += 1

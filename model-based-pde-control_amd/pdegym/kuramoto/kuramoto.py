@@ -9,14 +9,19 @@ raises; ``device=-1`` (``"cpu"``) asks for the library's CPU twin explicitly (BA
 
 Differences from the reference that a caller can observe:
   * ``env.u`` is a property backed by device memory (reads copy D2H, assignment copies H2D).
-  * ``reset`` runs its burn-in in the stepper's "exact" arithmetic mode by default, which is
-    bit-identical to the reference; ``step`` uses "fast" mode (<= 1e-12 per sub-step; contract
-    1e-9).  Both are selectable (``step_mode`` / ``reset_mode``).
+  * Arithmetic modes (``step_mode`` / ``reset_mode``): "fast" (merged stencil, FMAs: <= 1e-12 from the reference per
+    sub-step; the contract is 1e-9 per sub-step) is the default of BOTH since round 3; "exact" keeps the reference's
+    operation order and is bit-identical to it -- including a seeded ``reset()``, whose 200 000 chaotic sub-steps
+    amplify fast mode's 1e-16 rounding differences to O(1e-3), i.e. a different but statistically equivalent
+    realisation of the same attractor.  The burn-in is two thirds of all sub-steps of a run and exact arithmetic costs
+    2.6x (2.13 vs 0.83 ms per 250 sub-steps at 4096 x 256), so the default follows the per-sub-step contract;
+    ``reset_mode="exact"`` or ``PDEGYM_RESET_MODE=exact`` is the parity switch (every parity test passes it).
   * ``objective=""`` (the ``dissipation`` reward) raises in ``step`` here with NotImplementedError;
     in the reference it raises TypeError (FuncTransform hands tensors to scipy), so no working
     behaviour is lost.  ``reward_func`` itself is provided for both objectives.
 """
 import math
+import os
 from typing import Dict, List
 
 import numpy as np
@@ -24,6 +29,14 @@ import torch
 
 from pdegym._gym import gym
 from pdegym.common.transforms import FuncTransform, GaussianForcing
+
+
+def default_reset_mode() -> str:
+    """Arithmetic of the reset burn-in when the constructor is not told: ``PDEGYM_RESET_MODE`` or "fast"."""
+    mode = os.environ.get("PDEGYM_RESET_MODE", "fast").strip().lower()
+    if mode not in ("fast", "exact"):
+        raise ValueError(f"PDEGYM_RESET_MODE must be 'fast' or 'exact', not {mode!r}")
+    return mode
 
 
 class KuramotoSivashinskyEnv(gym.Env):
@@ -50,11 +63,12 @@ class KuramotoSivashinskyEnv(gym.Env):
         objective: str = "dissipation",
         device: int = 0,
         step_mode: str = "fast",
-        reset_mode: str = "exact",
+        reset_mode: str = None,
         variant: str = "auto",
         _stepper_cls=None,
     ):
         super().__init__()
+        reset_mode = reset_mode or default_reset_mode()
         self.L, self.N, self.cfg_steps = L, N, cfg_steps
         self.Ttrans, self.Tmax, self.dt = Ttrans, Tmax, dt
         self.noise, self.sigma, self.lmbda, self.objective = noise, sigma, lmbda, objective

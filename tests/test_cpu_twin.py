@@ -168,7 +168,7 @@ def test_configs0_single_env_random_action_rollout_on_cpu(ks_golden):
     import pdegym  # noqa: F401
     from pdegym._gym import gym
     from pdegym.kuramoto import ENV_ID, KuramotoSivashinskyEnv
-    env = gym.make(ENV_ID, config={"device": -1})
+    env = gym.make(ENV_ID, config={"device": -1, "reset_mode": "exact"})
     base = env.unwrapped
     assert base.N == 64 and base.L == 22.0 and base.max_episode_steps == 400
     # seeded reset == the reference's reset (200 000 sub-steps in exact arithmetic; ~3 s on one core)

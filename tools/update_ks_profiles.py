@@ -3,7 +3,8 @@
 gpurun_out/sq_<tag>/summary.json) into profiles/ks_pmc_traffic.json / profiles/ks_sq_counters.json, stamped with the
 identity of the kernel sources they were measured on (bench.py quotes them only while that identity is current).
 
-usage: tools/update_ks_profiles.py <workload c2|c3> <tag>"""
+usage: tools/update_ks_profiles.py <workload c2|c3> <tag> [key] [extra bench args, e.g. "--mode exact"]
+(key: the entry's name in the json files, default = the workload; "c3_exact" for the exact-mode kernel)"""
 import json
 import os
 import sys
@@ -13,9 +14,10 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 workload, tag = sys.argv[1], sys.argv[2]
+key = sys.argv[3] if len(sys.argv) > 3 else workload
 E, N, L, _ = bench.WORKLOADS[workload]
 sha = bench.kernel_source_sha()
-args = "--no-cpu-baseline --no-tbptt --no-secondary --workload " + workload
+args = "--no-cpu-baseline --no-tbptt --no-secondary --no-extras --workload " + workload + "".join(" " + a for a in sys.argv[4:])
 
 
 def merge(path, entry):
@@ -23,7 +25,7 @@ def merge(path, entry):
         data = json.load(open(path))
     except (OSError, ValueError):
         data = {}
-    data[workload] = entry
+    data[key] = entry
     json.dump(data, open(path, "w"), indent=1)
 
 
