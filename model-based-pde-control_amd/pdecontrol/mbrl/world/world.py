@@ -293,7 +293,10 @@ class WorldVecEnv(BaseWorldVecEnv):
         if self.device_resident is None:
             from pdecontrol.surrogates import ops
             dev = _surrogate_device(self.surrogate)
-            self.device_resident = bool(dev.type == "cuda" and ops.fused_enabled() and self.batched_reward_func is not None)
+            from pdecontrol.surrogates import hipops
+            members = _members(self.surrogate)[0]
+            self.device_resident = bool(dev.type == "cuda" and ops.fused_enabled() and self.batched_reward_func is not None
+                                        and all(hipops.fused_supported(m) for m in members))
         return self.device_resident
 
     def setup(self, starting: Dataset):

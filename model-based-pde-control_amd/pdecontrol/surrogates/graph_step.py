@@ -176,7 +176,7 @@ class GraphedTBPTTStep:
 
     def _fused(self):
         from pdecontrol.surrogates import ops
-        return ops.use_fused(self.states)
+        return ops.use_fused_for(self.module.surrogate, self.states)
 
     def _fwd_bwd(self):
         if not self.adam_in_flush:
@@ -202,6 +202,16 @@ class GraphedTBPTTStep:
         with torch.cuda.stream(self.stream):
             for _ in range(warmup):
                 self._fwd_bwd()
+            if self.autotune and self.used_pipelined:
+                # the schedule autotune (_capture) also captures the combined (autograd) schedule: it gets its eager
+                # passes here too, so that nothing persistent -- the unit root gradient, the packs' partial-gradient rows
+                # at the size THAT schedule needs, the autograd graph's buffers -- is first allocated under capture
+                self.pipelined = False
+                try:
+                    for _ in range(max(1, min(warmup, 2))):
+                        self._fwd_bwd()
+                finally:
+                    self.pipelined = self.used_pipelined = True
             packs = getattr(self.module.surrogate, "_fused_packs", None)
             if packs is not None and self._fused() and not self.distributed:
                 # fused kernels, single GPU: the flush launches take the Adam step.  The descriptors (the surrogate's

@@ -498,6 +498,9 @@ class PackAdam(torch.optim.Optimizer):
                 loss = closure()
         packs = self._packs()
         group = self.param_groups[0]
+        pending = self.__dict__.pop("_pending_state", None)
+        if pending is not None:
+            self._apply_pack_state(packs, pending)
         key = (id(packs), tuple(group["betas"]), group["eps"])
         if self.__dict__.get("_desc_key") != key:       # descriptors are built once; only the device lr changes per step
             self._descs, self._desc_key = packs.adam_descriptors(group["lr"], group["betas"], group["eps"]), key
@@ -540,14 +543,30 @@ class PackAdam(torch.optim.Optimizer):
     def load_state_dict(self, state):
         for g, saved in zip(self.param_groups, state.get("param_groups", [])):
             g.update(saved)
+        if not state.get("packs"):
+            return
         packs = getattr(self._surrogate, "_fused_packs", None)
-        if packs is not None and state.get("packs"):
-            packs.adam_descriptors(self.param_groups[0]["lr"])
-            for pack, saved in zip(packs.packs, state["packs"]):
-                if saved is not None:
-                    pack._adam_state[0].copy_(saved["exp_avg"])
-                    pack._adam_state[1].copy_(saved["exp_avg_sq"])
-                    pack._adam_state[2].fill_(int(saved["step"]))
+        if packs is None:
+            # a checkpoint is restored before the first forward pass, i.e. before the packs exist: keep the moments and
+            # hand them over when the first step() finds the packs (dropping them would restart Adam from zero, silently)
+            self._pending_state = [None if s is None else {k: (v.clone() if torch.is_tensor(v) else v) for k, v in s.items()}
+                                   for s in state["packs"]]
+            return
+        self._apply_pack_state(packs, state["packs"])
+
+    def _apply_pack_state(self, packs, saved_packs):
+        if len(saved_packs) != len(packs.packs):
+            raise SurrogateHipError(f"PackAdam state has {len(saved_packs)} packs, the surrogate {len(packs.packs)}")
+        group = self.param_groups[0]
+        packs.adam_descriptors(group["lr"], group["betas"], group["eps"])
+        for pack, saved in zip(packs.packs, saved_packs):
+            if saved is None:
+                continue
+            if saved["exp_avg"].numel() != pack._adam_state[0].numel():
+                raise SurrogateHipError("PackAdam state does not fit this surrogate (different parameter count)")
+            pack._adam_state[0].copy_(saved["exp_avg"])
+            pack._adam_state[1].copy_(saved["exp_avg_sq"])
+            pack._adam_state[2].fill_(int(saved["step"]))
 
 
 def fused_supported(surrogate):

@@ -2,17 +2,23 @@
 
 Every block of the surrogate goes through one of the functions below.  On CPU tensors they are
 plain torch (this is also the fp32 torch reference the HIP kernels are tested against).  On CUDA
-tensors the hand-written gfx950 kernels of libsurrogate_hip.so are THE path: they are on by default,
-the library's absence raises at the first CUDA tensor, and a surrogate whose geometry the kernels do
-not cover raises ``SurrogateHipError`` instead of quietly running PyTorch-ROCm / MIOpen kernels.  The
-plain torch-on-GPU path still exists as an explicit opt-out (``enable_fused(False)``, the
+tensors the hand-written gfx950 kernels of libsurrogate_hip.so are THE path for the architecture they implement
+(``hipops.fused_supported``: the reference's KSAutoRegConvolutionalLSTM layout at any N): they are on by default and
+the library's absence raises at the first CUDA tensor.  Every call site asks ``use_fused_for(surrogate, tensor)``: an
+architecture the kernels do not cover -- the reference also ships ``KSAutoRegFullyConnectedLSTM`` and trains it on the
+GPU as it is -- runs the plain PyTorch-ROCm path, announced ONCE per class through ``logging`` (never silently, and
+never the other way round: a covered architecture cannot end up on torch kernels without the explicit opt-out).  The
+plain torch-on-GPU path also exists as an explicit opt-out (``enable_fused(False)``, the
 ``fused(False)`` context manager or ``PDECONTROL_FUSED=0``): it is the same-device cross-check of the
 parity tests and the "hipGraph over torch kernels" leg of the benchmark.
 """
+import logging
 import os
 
 import torch
 
+_LOG = logging.getLogger("pdecontrol.surrogates")
+_NOTIFIED = set()
 _DEFAULT = os.environ.get("PDECONTROL_FUSED", "1") != "0"
 _FUSED = {"enabled": _DEFAULT, "lib": None}
 
@@ -57,6 +63,22 @@ def use_fused(tensor):
         from pdecontrol.surrogates import hipops
         _FUSED["lib"] = hipops.load()   # raises when the library has not been built: no silent fallback
     return True
+
+
+def use_fused_for(surrogate, tensor):
+    """``use_fused(tensor)`` for a surrogate the fused kernels implement; for any other architecture False, with one
+    logged notice per class (it then runs on PyTorch-ROCm kernels, as in the reference)."""
+    if not (_FUSED["enabled"] and tensor.is_cuda):
+        return False
+    from pdecontrol.surrogates import hipops
+    if hipops.fused_supported(surrogate):
+        return use_fused(tensor)
+    name = type(surrogate).__name__ + "/" + type(getattr(surrogate, "transition_model", None)).__name__
+    if name not in _NOTIFIED:
+        _NOTIFIED.add(name)
+        _LOG.warning("%s is not the architecture the fused HIP kernels implement (KSAutoRegConvolutionalLSTM layout): "
+                     "it runs on plain PyTorch-ROCm kernels", name)
+    return False
 
 
 def require_plain_path(tensor, what):

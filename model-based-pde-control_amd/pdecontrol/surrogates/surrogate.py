@@ -107,7 +107,7 @@ class AutoRegPDESurrogate(_EncDecSurrogate):
 
     def rollout(self, states: torch.Tensor, actions: torch.Tensor, times: torch.Tensor, targets: torch.Tensor,
                 hidden=None, **kwargs) -> ModelRollout:
-        if ops.use_fused(states):
+        if ops.use_fused_for(self, states):
             # one launch per module instead of ~60 per time step (no inlatents in this mode)
             from pdecontrol.surrogates import hipops
             return hipops.fused_rollout(self, states, actions, times, targets, hidden)

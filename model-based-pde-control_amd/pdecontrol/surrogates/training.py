@@ -81,7 +81,7 @@ class PDETrainingModule(pl.LightningModule):
         """Chunks of ``tbtt`` steps; chunk 0 warms up on the first ``tau`` true states, later chunks
         start from the previous chunk's last prediction with gradients cut (state and hidden)."""
         from pdecontrol.surrogates import ops
-        if ops.use_fused(states) and isinstance(self.surrogate, AutoRegPDESurrogate):
+        if isinstance(self.surrogate, AutoRegPDESurrogate) and ops.use_fused_for(self.surrogate, states):
             # every chunk in a handful of launches, independent work on parallel streams (hipops._TBPTTFn)
             from pdecontrol.surrogates import hipops
             outputs, deltas, hidden, d_all = hipops.fused_tbptt(self.surrogate, states, actions, self.tau, self.tbtt)
@@ -130,7 +130,7 @@ class PDETrainingModule(pl.LightningModule):
         MSELoss(reduction="none"), affine undscaling, fused kernels) or the sequence is a single chunk."""
         from pdecontrol.surrogates import ops
         states, actions, *_ = batch
-        if not (ops.use_fused(states) and isinstance(self.surrogate, AutoRegPDESurrogate)) or self.training_mode != "delta":
+        if not (isinstance(self.surrogate, AutoRegPDESurrogate) and ops.use_fused_for(self.surrogate, states)) or self.training_mode != "delta":
             return None
         if not (isinstance(self.loss, torch.nn.MSELoss) and self.loss.reduction == "none"):
             return None
@@ -169,7 +169,7 @@ class PDETrainingModule(pl.LightningModule):
         ``loss.backward()``.  None when the configuration is not the controller's (then the launch-by-launch path runs)."""
         from pdecontrol.surrogates import ops
         states, actions, *_ = batch
-        if not (ops.use_fused(states) and isinstance(self.surrogate, AutoRegPDESurrogate)) or self.training_mode != "delta":
+        if not (isinstance(self.surrogate, AutoRegPDESurrogate) and ops.use_fused_for(self.surrogate, states)) or self.training_mode != "delta":
             return None
         if not (isinstance(self.loss, torch.nn.MSELoss) and self.loss.reduction == "none"):
             return None

@@ -187,7 +187,9 @@ class ScaleTransform(Transform):
     @staticmethod
     def _affine(t, a, b, c, d):
         out = t - a
-        if out.shape == t.shape and out.dtype == (out[:0] / (b - a)).dtype:
+        # in place only for >= 1-D results whose dtype the division keeps (0-d inputs -- torch scalars, np.float32 --
+        # cannot be sliced for the probe and gain nothing from it)
+        if getattr(out, "ndim", 0) > 0 and out.shape == t.shape and out.dtype == (out[:0] / (b - a)).dtype:
             out /= (b - a)
             out *= (d - c)
             out += c

@@ -388,3 +388,71 @@ def test_pack_adam_matches_torch_adam_and_lightning_closure_order(dev):
         np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), rtol=2e-5, atol=1e-6, err_msg=name)
     sd = opt.state_dict()
     assert sd["packs"][2]["step"] == 5 and sd["param_groups"][0]["lr"] == 2.5e-4
+
+
+def test_pack_adam_state_restored_before_the_first_forward(dev):
+    """A checkpoint is loaded before the packs exist (Lightning restores optimizer states before the first batch): the
+    moments and the step counter must survive and the continued run must equal the uninterrupted one."""
+    from pdecontrol.surrogates import hipops
+    from pdecontrol.surrogates.bench_tbptt import build_module, synthetic_batch
+    batch = synthetic_batch(B=8, device=dev)
+
+    def steps(mod, opt, n):
+        for _ in range(n):
+            out = mod.training_step(batch, 0)
+            opt.zero_grad(set_to_none=True)
+            out["loss"].backward()
+            opt.step()
+
+    a = build_module(dev)
+    opt_a = a.configure_optimizers()[0][0]
+    steps(a, opt_a, 3)
+    weights = {k: v.detach().clone() for k, v in a.surrogate.state_dict().items()}
+    saved = opt_a.state_dict()
+    steps(a, opt_a, 2)                                      # the uninterrupted run: 5 steps
+    b = build_module(dev, seed=123)
+    b.surrogate.load_state_dict(weights)
+    opt_b = b.configure_optimizers()[0][0]
+    assert isinstance(opt_b, hipops.PackAdam) and getattr(b.surrogate, "_fused_packs", None) is None
+    opt_b.load_state_dict(saved)                            # no packs yet
+    steps(b, opt_b, 2)
+    torch.cuda.synchronize(dev)
+    assert b.surrogate._fused_packs.adam_step_count() == 5
+    for (name, p), q in zip(b.surrogate.named_parameters(), a.surrogate.parameters()):
+        np.testing.assert_array_equal(p.detach().cpu().numpy(), q.detach().cpu().numpy(), err_msg=name)
+
+
+def test_fully_connected_lstm_factory_trains_on_cuda_under_the_defaults(dev, caplog):
+    """The reference also ships KSAutoRegFullyConnectedLSTM (architectures/autoreg.py) and trains it on the GPU as it is.
+    The fused kernels do not implement it: under the DEFAULT settings it must run (plain PyTorch-ROCm kernels, one logged
+    notice) -- rollout, training_step, backward, optimizer step -- and agree with the CPU."""
+    import logging
+    from pdecontrol.architectures import KSAutoRegFullyConnectedLSTM
+    from pdecontrol.surrogates import hipops, ops
+    from pdecontrol.surrogates.training import PDETrainingModule
+    assert ops.fused_enabled()
+
+    def build(device):
+        torch.manual_seed(0)
+        f = KSAutoRegFullyConnectedLSTM()
+        sur = f.surrogate(delta=0.25, dscaling=None, tau=5, **f.model())
+        return PDETrainingModule(surrogate=sur, loss=torch.nn.MSELoss(reduction="none"), tstep=0.25, delta=0.25, tau=5,
+                                 tbtt=10).to(device)
+
+    g = torch.Generator().manual_seed(1)
+    s, a = torch.rand(4, 20, 1, 64, generator=g) * 2 - 1, torch.rand(4, 20, 1, 64, generator=g) * 2 - 1
+    cpu, gpu = build("cpu"), build(dev)
+    assert not hipops.fused_supported(gpu.surrogate)
+    with caplog.at_level(logging.WARNING, logger="pdecontrol.surrogates"):
+        out = gpu.training_step((s.to(dev), a.to(dev)), 0)
+    assert any("plain PyTorch-ROCm" in r.message for r in caplog.records)
+    opt = gpu.configure_optimizers()[0][0]
+    assert not isinstance(opt, hipops.PackAdam)
+    opt.zero_grad(set_to_none=True)
+    out["loss"].backward()
+    opt.step()
+    ref = cpu.training_step((s, a), 0)
+    np.testing.assert_allclose(float(out["loss"].detach()), float(ref["loss"].detach()), rtol=1e-5)
+    times = 0.25 * torch.arange(10)
+    r = gpu.surrogate.rollout(states=s[:, :5].to(dev), actions=a[:, :10].to(dev), times=times, targets=times + 0.25)
+    assert r.outputs.shape == (4, 10, 1, 64) and torch.isfinite(r.outputs).all()

@@ -57,6 +57,9 @@ def test_scale_transform_roundtrip_and_update():
     b.update(torch.full((1, 1, 3), 10.0))
     assert float(b.vmax) == 1.0
     np.testing.assert_allclose(b(np.array([0.0], dtype=np.float32)), [0.5])
+    # 0-d inputs (np.float32, 0-d arrays, torch scalars) as the reference's expression handles them
+    assert float(b(np.float32(0.5))) == 0.75 and float(b(np.asarray(-1.0, dtype=np.float32))) == 0.0
+    assert float(b(torch.tensor(0.5))) == 0.75 and float(b.Inverse(torch.tensor(0.75))) == 0.5
 
 
 def test_sensor_func_identity_operation_batch():
