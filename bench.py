@@ -243,24 +243,26 @@ class KSRun:
                                  d_ssq=self.d_ssq.data_ptr(), d_status=self.d_st.data_ptr())
 
     def timed(self, K, W, barrier):
-        """W warm-up launches, then K launches bracketed by barrier(); returns (elapsed s, mean launch ms from HIP
-        events recorded on the launch stream)."""
+        """W warm-up launches, then K launches bracketed by barrier(); returns (elapsed s, mean launch ms from ONE pair of
+        HIP events recorded on the launch stream around the K back-to-back launches).  Round 2 recorded a pair PER launch:
+        every record is a barrier packet that drains the queue before the next dispatch, which cost 5 % (C3) to 13 % (C2)
+        of the very time being measured (tools/ks_substep_sweep.py: same box, same launches, no events in between)."""
         with torch.cuda.stream(self.stream):
             for i in range(W):
                 self.one_step(i)
             barrier()
-            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             t0 = time.perf_counter()
+            e0.record(self.stream)
             for i in range(K):
-                ev[i][0].record(self.stream)
                 self.one_step(W + i)
-                ev[i][1].record(self.stream)
+            e1.record(self.stream)
             barrier()
             elapsed = time.perf_counter() - t0
             self.st_acc |= self.d_st
         torch.cuda.synchronize(self.dev)
         assert int(self.st_acc.sum()) == 0, "non-finite state during the benchmark"
-        return elapsed, float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        return elapsed, e0.elapsed_time(e1) / K
 
 
 def end_to_end_leg(run, K=20, W=3):
@@ -322,6 +324,37 @@ def episode_leg(run, reset_mode, ring=8):
                       "ic_draw_on_host_ms_not_included": ic_ms}}
 
 
+VALU_ISSUE_PEAK = 1024 * 2.4e9 / 4 / 1e9     # G wave-instructions/s: 256 CUs x 4 SIMDs, one wave64 VALU op per 4 cycles, 2.4 GHz
+
+
+def burgers_roofline(E, N, cfg_steps, ms):
+    """The Burgers stepper keeps its state in VGPRs for all sub-steps of a launch: HBM is not what bounds it (the 12*N
+    streaming model would read as 2.5x the HBM peak -- not a roofline).  The binding resource is VALU issue: every wave64
+    VALU instruction holds its SIMD for >= 4 cycles, so achieved = wave-instructions per second (SQ_INSTS_VALU per
+    launch from profiles/burgers_sq_counters.json / this run's launch time) against 1024 SIMDs x 2.4 GHz / 4."""
+    alg = 12.0 * N * E * cfg_steps
+    out = {"bound": "valu_issue", "achieved": None, "peak": VALU_ISSUE_PEAK, "unit": "G wave-instructions/s", "frac": None,
+           "hbm_streaming_model_gbs": alg / (ms * 1e-3) / 1e9,
+           "note": "fp32 stencil with the state in registers for all 50 sub-steps of a launch: VALU-issue bound; the 12*N B "
+                   "per env-sub-step streaming figure is kept as a rate only, it is not a bound for this kernel"}
+    try:
+        sq = json.load(open(os.path.join(ROOT, "profiles", "burgers_sq_counters.json")))["c4"]
+        sha = hashlib.sha256(open(os.path.join(ROOT, "model-based-pde-control_amd", "csrc", "burgers.hip"), "rb").read()).hexdigest()[:16]
+        if sq.get("kernel_source_sha") == sha:
+            per_point = sq["valu_instructions_per_point_substep"]
+            insts = per_point * E * N * cfg_steps / 64.0
+            out["achieved"] = insts / (ms * 1e-3) / 1e9
+            out["frac"] = out["achieved"] / VALU_ISSUE_PEAK
+            out["valu_instructions_per_point_substep"] = per_point
+            out["valu_busy_frac_of_wave_cycles"] = sq.get("fractions_of_wave_cycles", {}).get("SQ_ACTIVE_INST_VALU")
+            out["source"] = "profiles/burgers_sq_counters.json (rocprofv3 --pmc SQ_INSTS_VALU, kernel sources unchanged since)"
+        else:
+            out["source"] = "profiles/burgers_sq_counters.json is STALE (burgers.hip changed since): fraction not quoted"
+    except (OSError, ValueError, KeyError):
+        out["source"] = "no SQ counters on file: fraction not quoted"
+    return out
+
+
 def burgers_fno_leg(dev, steps=30, warmup=5):
     """BASELINE configs[4] (second PDE path; the reference ships neither a Burgers env nor an FNO, so nothing here has a
     reference-side pin beyond the discretisation, tests/test_burgers.py): the fp32 Burgers stepper at 512 grid points and
@@ -333,22 +366,18 @@ def burgers_fno_leg(dev, steps=30, warmup=5):
     acts = torch.from_numpy(np.random.RandomState(5).uniform(-1, 1, (steps + warmup, E, 4)).astype(np.float32)).to(dev)
     for i in range(warmup):
         env.step_torch(acts[i])
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     for i in range(steps):
-        ev[i][0].record()
         env.step_torch(acts[warmup + i])
-        ev[i][1].record()
+    e1.record()
     torch.cuda.synchronize(dev)
     assert int(env._status.sum()) == 0
-    ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    alg = 12.0 * N * E * env.cfg_steps           # fp32: read u, write u, read phi per env-sub-step
+    ms = e0.elapsed_time(e1) / steps
     out = {"workload": f"Burgers nu={env.nu} N={N} dt={env.dt} cfg_steps={env.cfg_steps}, {E} batched envs (BASELINE.json configs[4], "
                        f"one GPU's share), fp32",
            "value": E * env.cfg_steps / (ms * 1e-3), "unit": "sub-steps/s", "avg_launch_ms": ms,
-           "roofline": {"bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg,
-                        "note": "algorithmic 12*N B per env-sub-step (fp32 u in, u out, phi); state in VGPRs for all 50 "
-                                "sub-steps, so like the KS stepper the kernel is VALU-issue bound, not HBM bound"}}
+           "roofline": burgers_roofline(E, N, env.cfg_steps, ms)}
     # FNO surrogate: eager training_step + backward + Adam, B = 64, T = 20, N = 512 (width 32, 16 modes, 4 layers)
     from pdecontrol.architectures import BurgersFNO
     from pdecontrol.surrogates.training import PDETrainingModule

@@ -41,3 +41,40 @@ def _default_cuda_path():
     ops.reset_fused()
     yield
     ops.reset_fused()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# gradient parity against the reference's recorded gradients (pdecontrol/surrogates/training.py:64-130 backward)
+# ---------------------------------------------------------------------------------------------------------------------
+#: per-tensor tolerance on max|g - g_ref| / max|g_ref| (the error relative to the TENSOR's scale: single near-zero entries
+#: of a gradient carry fp32 summation-order noise of the whole contraction, so an element-wise rtol says nothing).
+#: Set at <= 10x the largest value observed on MI355X (profiles/r03_grad_parity_observed.json, tools/grad_parity_report.py).
+GRAD_TOL = 2e-4
+GRAD_LOG = os.path.join(ROOT, "gpurun_out", "grad_parity_observed.jsonl")
+
+
+def check_grads(label, grads, ref_of, tol=None):
+    """grads: {parameter name: array}; ref_of(name) -> the reference's gradient.  Asserts every tensor within ``tol`` of
+    the reference relative to that tensor's scale, and appends the observed maxima per parameter group to GRAD_LOG."""
+    import json
+    tol = GRAD_TOL if tol is None else tol
+    groups, worst = {}, (0.0, None)
+    for name, got in grads.items():
+        ref = np.asarray(ref_of(name))
+        got = np.asarray(got)
+        assert got.shape == ref.shape, (name, got.shape, ref.shape)
+        scale = float(np.abs(ref).max())
+        err = float(np.abs(got - ref).max()) / scale if scale > 0 else float(np.abs(got).max())
+        grp = name.split(".")[0]
+        groups[grp] = max(groups.get(grp, 0.0), err)
+        if err > worst[0]:
+            worst = (err, name)
+    rec = {"label": label, "max_err_over_tensor_scale": groups, "worst": {"name": worst[1], "err": worst[0]}, "tol": tol}
+    print("grad parity", json.dumps(rec))
+    try:
+        os.makedirs(os.path.dirname(GRAD_LOG), exist_ok=True)
+        with open(GRAD_LOG, "a") as f:
+            f.write(json.dumps(rec) + "\n")
+    except OSError:
+        pass
+    assert worst[0] <= tol, f"{label}: {worst[1]} off by {worst[0]:.3e} of its scale (tolerance {tol:.1e})"

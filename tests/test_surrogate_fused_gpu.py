@@ -144,11 +144,10 @@ def test_fused_training_step_matches_unfused_and_golden(dev, sur_golden):
             assert rel < 1e-5, rel
             np.testing.assert_allclose(res["outputs"].cpu().numpy(), g[f"{tag}_outputs"], rtol=1e-3, atol=1e-4)
             np.testing.assert_allclose(res["outdeltas"].cpu().numpy(), g[f"{tag}_outdeltas"], rtol=1e-3, atol=1e-4)
-            for k, p in m.surrogate.named_parameters():
-                if p.requires_grad:
-                    ref = g[f"{tag}_grad/" + k]
-                    np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=1e-2,
-                                               atol=3e-5 * max(1.0, np.abs(ref).max()), err_msg=k)
+            from conftest import check_grads
+            check_grads(f"n64 {tag} fused vs golden (fused_gpu suite)",
+                        {k: p.grad.detach().cpu().numpy() for k, p in m.surrogate.named_parameters() if p.requires_grad},
+                        lambda k: g[f"{tag}_grad/" + k])
     finally:
         ops.reset_fused()
 
@@ -356,8 +355,9 @@ def test_fused_tbptt_other_chunkings(dev, T):
     _close(of["outputs"], ot["outputs"], rtol=1e-3, atol_scale=1e-4, msg="outputs")
     _close(of["hsteploss"], ot["hsteploss"], rtol=1e-4, atol_scale=1e-6, msg="hsteploss")
     assert gf.keys() == gt.keys()
-    for k in gt:
-        _close(gf[k], gt[k], rtol=1e-2, atol_scale=8e-5, msg=k)
+    from conftest import check_grads
+    check_grads(f"fused vs plain torch kernels, same device (T={T})",
+                {k: v.detach().cpu().numpy() for k, v in gf.items()}, lambda k: gt[k].detach().cpu().numpy())
 
 
 def test_pack_adam_matches_torch_adam_and_lightning_closure_order(dev):
@@ -440,7 +440,8 @@ def test_fully_connected_lstm_factory_trains_on_cuda_under_the_defaults(dev, cap
                                  tbtt=10).to(device)
 
     g = torch.Generator().manual_seed(1)
-    s, a = torch.rand(4, 20, 1, 64, generator=g) * 2 - 1, torch.rand(4, 20, 1, 64, generator=g) * 2 - 1
+    # this ablation consumes the raw 4 actuator values, not the forcing field
+    s, a = torch.rand(4, 20, 1, 64, generator=g) * 2 - 1, torch.rand(4, 20, 1, 4, generator=g) * 2 - 1
     cpu, gpu = build("cpu"), build(dev)
     assert not hipops.fused_supported(gpu.surrogate)
     with caplog.at_level(logging.WARNING, logger="pdecontrol.surrogates"):

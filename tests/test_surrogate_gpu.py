@@ -4,7 +4,13 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import check_grads
+
 pytestmark = pytest.mark.gpu
+
+
+def _named_grads(m):
+    return {k: p.grad.detach().cpu().numpy() for k, p in m.surrogate.named_parameters() if p.requires_grad and p.grad is not None}
 
 
 def _module(device, scaled=False, seed=0):
@@ -43,11 +49,7 @@ def test_training_step_parity_on_gpu(sur_golden, scaled, fused):
     np.testing.assert_allclose(res["hsteploss"].cpu().numpy(), g[f"{tag}_hsteploss"], rtol=1e-4)
     np.testing.assert_allclose(res["outputs"].cpu().numpy(), g[f"{tag}_outputs"], rtol=1e-3, atol=1e-4)
     np.testing.assert_allclose(res["outdeltas"].cpu().numpy(), g[f"{tag}_outdeltas"], rtol=1e-3, atol=1e-4)
-    for k, p in m.surrogate.named_parameters():
-        if p.grad is not None:
-            ref = g[f"{tag}_grad/" + k]
-            np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=1e-2, atol=2e-5 * max(1.0, np.abs(ref).max()),
-                                       err_msg=k)
+    check_grads(f"n64 {tag} training_step fused={fused}", _named_grads(m), lambda k: g[f"{tag}_grad/" + k])
 
 
 @pytest.mark.parametrize("fused", [False, True])
@@ -73,11 +75,7 @@ def test_known_answer_b64_on_gpu(sur_golden, fused):
         np.testing.assert_allclose(res["hsteploss"].cpu().numpy(), g["b64_hsteploss"], rtol=1e-4)
         gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.surrogate.parameters() if p.grad is not None)).item()
         assert abs(gn - float(g["b64_grad_norm"])) / float(g["b64_grad_norm"]) < 1e-3
-        for k, p in m.surrogate.named_parameters():
-            if p.requires_grad:
-                ref = g["b64_grad/" + k]
-                np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=1e-2, atol=3e-5 * max(1.0, np.abs(ref).max()),
-                                           err_msg=k)
+        check_grads(f"n64 b64 training_step fused={fused}", _named_grads(m), lambda k: g["b64_grad/" + k])
 
 
 def test_pipelined_training_pass_against_reference_b64(sur_golden):
@@ -95,11 +93,7 @@ def test_pipelined_training_pass_against_reference_b64(sur_golden):
     loss = res["loss"].item()
     assert abs(loss - 10.806351661682129) / 10.806351661682129 < 1e-5
     np.testing.assert_allclose(res["hsteploss"].cpu().numpy(), g["b64_hsteploss"], rtol=1e-4)
-    for k, p in m.surrogate.named_parameters():
-        if p.requires_grad:
-            ref = g["b64_grad/" + k]
-            np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=1e-2, atol=3e-5 * max(1.0, np.abs(ref).max()),
-                                       err_msg=k)
+    check_grads("n64 b64 pipelined pass", _named_grads(m), lambda k: g["b64_grad/" + k])
 
 
 @pytest.mark.parametrize("tbtt,T", [(10, 20), (7, 20), (6, 23)])
@@ -413,10 +407,7 @@ def test_n256_training_step_against_reference_fixture(fused, scaled):
     np.testing.assert_allclose(res["hsteploss"].cpu().numpy(), g[f"{tag}_hsteploss"], rtol=1e-4)
     np.testing.assert_allclose(res["outputs"].cpu().numpy(), g[f"{tag}_outputs"], rtol=1e-3, atol=1e-4)
     np.testing.assert_allclose(res["outdeltas"].cpu().numpy(), g[f"{tag}_outdeltas"], rtol=1e-3, atol=1e-4)
-    for k, p in m.surrogate.named_parameters():
-        if p.requires_grad:
-            ref = g[f"{tag}_grad/" + k]
-            np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=1e-2, atol=4e-5 * max(1.0, np.abs(ref).max()), err_msg=k)
+    check_grads(f"n256 {tag} training_step fused={fused}", _named_grads(m), lambda k: g[f"{tag}_grad/" + k])
 
 
 def test_n256_benchmarked_batch_b64_fused():
@@ -435,10 +426,7 @@ def test_n256_benchmarked_batch_b64_fused():
     rel = abs(res["loss"].item() - float(g["b64n_loss"])) / float(g["b64n_loss"])
     assert rel < 1e-5, rel
     np.testing.assert_allclose(res["hsteploss"].cpu().numpy(), g["b64n_hsteploss"], rtol=1e-4)
-    for k, p in m.surrogate.named_parameters():
-        if p.requires_grad:
-            ref = g["b64n_grad/" + k]
-            np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=1e-2, atol=4e-5 * max(1.0, np.abs(ref).max()), err_msg=k)
+    check_grads("n256 b64n training_step fused", _named_grads(m), lambda k: g["b64n_grad/" + k])
 
 
 def test_n256_pipelined_pass_b64_against_reference_fixture():
@@ -455,10 +443,7 @@ def test_n256_pipelined_pass_b64_against_reference_fixture():
     rel = abs(res["loss"].item() - float(g["b64n_loss"])) / float(g["b64n_loss"])
     assert rel < 1e-5, rel
     np.testing.assert_allclose(res["hsteploss"].cpu().numpy(), g["b64n_hsteploss"], rtol=1e-4)
-    for k, p in m.surrogate.named_parameters():
-        if p.requires_grad:
-            ref = g["b64n_grad/" + k]
-            np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=1e-2, atol=4e-5 * max(1.0, np.abs(ref).max()), err_msg=k)
+    check_grads("n256 b64n pipelined pass", _named_grads(m), lambda k: g["b64n_grad/" + k])
 
 
 def test_validation_and_test_step_on_gpu_against_reference_module():

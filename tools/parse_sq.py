@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Per-launch means of the SQ counters of ks_rk4_fused from a rocprofv3 --pmc CSV (tools/prof_sq.sh)."""
+"""Per-launch means of the SQ counters of ks_rk4_fused (or the kernels matching argv[3]) from a rocprofv3 --pmc CSV
+(tools/prof_sq.sh, tools/prof_sq_burgers.sh)."""
 import collections
 import csv
 import glob
@@ -8,11 +9,12 @@ import os
 import sys
 
 out_dir, tag = sys.argv[1], sys.argv[2]
+pattern = sys.argv[3] if len(sys.argv) > 3 else "ks_rk4_fused"
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(out_dir, "sq", "**", "*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
         name = row.get("Kernel_Name", "")
-        if "ks_rk4_fused" in name:
+        if pattern in name:
             vals[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
 summary = {"tag": tag, "kernels": {}}
 for name, ctrs in vals.items():
