@@ -346,7 +346,14 @@ def burgers_roofline(E, N, cfg_steps, ms):
             out["achieved"] = insts / (ms * 1e-3) / 1e9
             out["frac"] = out["achieved"] / VALU_ISSUE_PEAK
             out["valu_instructions_per_point_substep"] = per_point
-            out["valu_busy_frac_of_wave_cycles"] = sq.get("fractions_of_wave_cycles", {}).get("SQ_ACTIVE_INST_VALU")
+            busy = sq.get("fractions_of_wave_cycles", {}).get("SQ_ACTIVE_INST_VALU")
+            waves = sq.get("mean_per_launch", {}).get("SQ_WAVES")
+            out["valu_busy_frac_of_wave_cycles"] = busy
+            if busy and waves:
+                # SQ_WAVE_CYCLES sums over the waves resident on a SIMD: x waves per SIMD = how busy each SIMD's VALU is
+                out["valu_busy_per_simd"] = busy * waves / 1024.0
+                out["note"] += "; packed fp32 instructions (v_pk_*_f32) occupy the pipe for two passes, which is why the " \
+                               "VALU is busy nearly all cycles (valu_busy_per_simd) at this fraction of the single-pass issue peak"
             out["source"] = "profiles/burgers_sq_counters.json (rocprofv3 --pmc SQ_INSTS_VALU, kernel sources unchanged since)"
         else:
             out["source"] = "profiles/burgers_sq_counters.json is STALE (burgers.hip changed since): fraction not quoted"
@@ -617,11 +624,13 @@ def main():
             other = "c2" if args.workload == "c3" else "c3"
             try:
                 E2, N2, L2, idx2 = WORKLOADS[other]
-                sec = KSRun(kspde, other, local_rank, dev, rank, 20 + 3, args.mode)
-                el2, ms2 = sec.timed(20, 3, lambda: torch.cuda.synchronize(dev))
+                # enough launches for the clocks to settle after the headline workload (C2 launches are 0.1 ms)
+                K2, W2 = (200, 30) if other == "c2" else (30, 5)
+                sec = KSRun(kspde, other, local_rank, dev, rank, K2 + W2, args.mode)
+                el2, ms2 = sec.timed(K2, W2, lambda: torch.cuda.synchronize(dev))
                 out["workload_" + other] = {
                     "workload": f"KS L={L2:g} N={N2}, {E2} envs (BASELINE.json configs[{idx2}])",
-                    "value": E2 * CFG_STEPS * 20 / el2, "unit": "sub-steps/s", "avg_launch_ms": ms2, "kernel": sec.stepper.layout(),
+                    "value": E2 * CFG_STEPS * K2 / el2, "steps": K2, "unit": "sub-steps/s", "avg_launch_ms": ms2, "kernel": sec.stepper.layout(),
                     "roofline": roofline_of(other, E2, N2, ms2, sec.stepper.layout())}
                 del sec
             except Exception as exc:

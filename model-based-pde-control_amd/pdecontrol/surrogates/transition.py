@@ -104,7 +104,8 @@ class LSTMTransitionModel(TransitionModel):
     def teacherforcing(self, states, actions, hidden=None, **kwargs):
         bsize, steps = states.shape[:2]
         H, C = self._initial(bsize) if hidden is None else hidden
-        flat_s = states.reshape(bsize, steps, -1).swapaxes(0, 1)
+        # (.contiguous(): MIOpen's RNN refuses a strided h0, which the time-major view of [B, T, width] is; values unchanged)
+        flat_s = states.reshape(bsize, steps, -1).swapaxes(0, 1).contiguous()
         flat_a = actions.reshape(bsize, steps, -1)
         outputs = []
         for t in range(steps):

