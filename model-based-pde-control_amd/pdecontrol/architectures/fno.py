@@ -9,6 +9,10 @@ own conventions so that they plug into its training module and world env unchang
   ``next = prev + delta * dscaling(model(prev, action))``, teacher forced on the given states, free running afterwards,
   same integer path for action / target indices; stateless (``hidden`` is an empty tuple).  ``training_mode = "delta"``.
 * ``BurgersFNO``: the factory (``--factory BurgersFNO``), ``model(N=..., width=..., modes=..., layers=...)``.
+
+On CUDA tensors a rollout of the default geometry (width 32, 16 modes, 4 layers, N <= 512) runs on the whole-network HIP
+kernels (pdecontrol/surrogates/fno_hip.py, csrc/fno.hip): one launch per model evaluation and direction instead of ~170
+small kernels; any other geometry keeps the per-operator path below (fused spectral convolution + torch / rocBLAS).
 """
 import torch
 from torch import nn
@@ -92,6 +96,14 @@ class FNOAutoRegSurrogate(PDESurrogate):
         n_given = states.size(1)
         aidx, tidx = action_and_target_indices(times, targets, self.delta)
         acts = take_steps(actions, aidx.tolist())
+        from pdecontrol.surrogates import ops
+        if ops.use_fused(states):
+            from pdecontrol.surrogates import fno_hip
+            fused = fno_hip.rollout(self.model, states, acts, n_given, self.delta, self.dscaling)
+            if fused is not None:
+                deltas, outputs = fused
+                pick = tidx.tolist()
+                return ModelRollout(outlatents=None, deltas=take_steps(deltas, pick), outputs=take_steps(outputs, pick), hidden=())
         outdeltas, outputs = [], []
         output = states[:, 0]
         for k in range(acts.size(1)):

@@ -146,3 +146,90 @@ def test_fno_step_as_one_captured_graph():
     l_mod = [float(m.fused_step((st, ac))["loss"]) for _ in range(4)]
     np.testing.assert_allclose(l_mod, l_ref, rtol=2e-5)
     assert l_mod[-1] < l_mod[0] and len(m._graphed_steps) == 1
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# whole-network kernels (csrc/fno.hip): one launch per model evaluation.  Parity unpinned against the reference (it has
+# no FNO); pinned against the per-operator torch spelling of the same module.
+# ---------------------------------------------------------------------------------------------------------------------
+def test_fno_c_abi_exports():
+    from pdecontrol.surrogates import fno_hip
+    text = open(os.path.join(ROOT, "include", "spectral_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(fno_[a-z_]+)\s*\(", text)))
+    lib = ctypes.CDLL(spectral.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert sorted(n for n, _, _ in fno_hip.SYMBOLS) == declared
+    lib.fno_row_width.restype = ctypes.c_int
+    assert lib.fno_row_width() >= 96 + 4 * 1056 + 1089
+
+
+def _fno_pair(dev, n, scaled):
+    from pdegym.common.transforms import BatchTransform, Normalize
+    und = None
+    if scaled:
+        norm = Normalize(aggregate=True, batched=True)
+        norm.mean, norm.var, norm.count = torch.full((1, 1, 1), 0.02), torch.full((1, 1, 1), 0.3), 50
+        und = BatchTransform(norm)
+    mods = []
+    for device in ("cpu", dev):
+        torch.manual_seed(0)
+        f = BurgersFNO()
+        s = f.surrogate(delta=0.05, dscaling=None if und is None else und.Inverse, tau=5, **f.model())
+        mods.append(PDETrainingModule(surrogate=s, loss=torch.nn.MSELoss(reduction="none"), tstep=0.05, delta=0.05,
+                                      undscaling=und, tau=5, tbtt=10).to(device))
+    return mods
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,scaled,B,T", [(512, False, 4, 20), (128, True, 3, 13), (64, False, 2, 7)])
+def test_whole_network_kernels_training_step_vs_cpu(n, scaled, B, T):
+    """training_step + backward through the whole-network kernels (teacher-forced launch + free-running chain, two TBPTT
+    chunks at T = 20) against the same module on the CPU: loss <= 1e-5 relative (north_star's TBPTT tolerance), every
+    parameter gradient to fp32 summation noise of its tensor's scale."""
+    from conftest import check_grads
+    from pdecontrol.surrogates import fno_hip
+    dev = torch.device("cuda", 0)
+    cpu, gpu = _fno_pair(dev, n, scaled)
+    assert fno_hip.supported(gpu.surrogate.model, n)
+    g = torch.Generator().manual_seed(n + T)
+    st, ac = torch.rand(B, T, 1, n, generator=g) * 2 - 1, torch.rand(B, T, 1, n, generator=g) * 2 - 1
+    ref = cpu.training_step((st, ac), 0)
+    ref["loss"].backward()
+    calls = []
+    orig = fno_hip._FNORolloutFn.apply
+    fno_hip._FNORolloutFn.apply = lambda *a: (calls.append(1), orig(*a))[1]
+    try:
+        out = gpu.training_step((st.to(dev), ac.to(dev)), 0)
+    finally:
+        fno_hip._FNORolloutFn.apply = orig
+    assert len(calls) == (2 if T > 10 else 1), "the rollout must run on the whole-network kernels, one node per chunk"
+    out["loss"].backward()
+    torch.cuda.synchronize(dev)
+    rel = abs(float(out["loss"].detach()) - float(ref["loss"].detach())) / abs(float(ref["loss"].detach()))
+    assert rel < 1e-5, rel
+    np.testing.assert_allclose(out["outputs"].detach().cpu().numpy(), ref["outputs"].detach().numpy(), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(out["outdeltas"].detach().cpu().numpy(), ref["outdeltas"].detach().numpy(), rtol=1e-4, atol=2e-5)
+    check_grads(f"FNO whole-network kernels vs CPU (N={n}, scaled={scaled})",
+                {k: p.grad.detach().cpu().numpy() for k, p in gpu.surrogate.named_parameters()},
+                dict((k, p.grad.numpy()) for k, p in cpu.surrogate.named_parameters()).__getitem__, tol=2e-4)
+
+
+@pytest.mark.gpu
+def test_whole_network_rollout_inference_and_fallback_geometry():
+    from pdecontrol.surrogates import fno_hip
+    dev = torch.device("cuda", 0)
+    cpu, gpu = _fno_pair(dev, 256, True)
+    g = torch.Generator().manual_seed(9)
+    st, ac = torch.rand(5, 3, 1, 256, generator=g) * 2 - 1, torch.rand(5, 7, 1, 256, generator=g) * 2 - 1
+    times, targets = 0.05 * torch.arange(7), 0.05 * (torch.arange(7) + 1)
+    with torch.no_grad():
+        r_cpu = cpu.surrogate.rollout(states=st, actions=ac, times=times, targets=targets)
+        r_gpu = gpu.surrogate.rollout(states=st.to(dev), actions=ac.to(dev), times=times, targets=targets)
+    np.testing.assert_allclose(r_gpu.outputs.cpu().numpy(), r_cpu.outputs.numpy(), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(r_gpu.deltas.cpu().numpy(), r_cpu.deltas.numpy(), rtol=1e-4, atol=2e-5)
+    # a geometry the whole-network kernels are not built for keeps the per-operator path (and still works)
+    small = _module(dev, n=128)            # width 16, 8 modes, 2 layers
+    assert not fno_hip.supported(small.surrogate.model, 128)
+    out = small.training_step(((torch.rand(2, 12, 1, 128, generator=g) * 2 - 1).to(dev), (torch.rand(2, 12, 1, 128, generator=g) * 2 - 1).to(dev)), 0)
+    assert torch.isfinite(out["loss"])
