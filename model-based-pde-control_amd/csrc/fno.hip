@@ -107,6 +107,17 @@ __device__ __forceinline__ float gelu_grad(float x) {
     return fmaf(x * 0.3989422804014327f, __expf(-0.5f * x * x), cdf);
 }
 
+// diagnostic build (-DFNO_STAMP, tools/fno_stamp_run.py): shader-clock stamps of workgroup 0 at the phase boundaries
+#ifdef FNO_STAMP
+__device__ unsigned long long g_stamps[256];
+#define STAMP(k)                                                                      \
+    do {                                                                              \
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_stamps[(k)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
 struct Lds {
     float *xs, *tb, *S, *Z, *wps, *gv, *ctab, *misc;
     int NP;
@@ -186,6 +197,60 @@ __device__ __forceinline__ void lift_into(float* xs, const float* u, const float
     }
 }
 
+// Complex mode mixing of one pair, 512 threads: thread (row, m4, q4) owns 4 consecutive modes of output row `row` and a
+// quarter of the 32-term contraction (16-byte weight loads: a quarter of the load instructions of one (row, mode) per
+// thread; this phase is latency bound), the quarters are folded by lane shuffles.
+//   forward  (CONJ = false): out[o][m] = s_m sum_i in[i][m] W[i][o][m]          in = S (summed over its K-split halves)
+//   backward (CONJ = true) : out[i][m] =     sum_o in[o][m] conj(W[i][o][m])    in = Z (one copy)
+// Spectra rows are [re 0..15 | im 0..15].
+template <bool CONJ>
+__device__ __forceinline__ void mix_modes(const float* __restrict__ wr, const float* __restrict__ wi, const float* in, float* out,
+                                          float s0, float s1) {
+    const int t = threadIdx.x, q4 = t & 3, m4 = (t >> 2) & 3, row = t >> 4;
+    float yr[4] = {0.f, 0.f, 0.f, 0.f}, yi[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c8 = 0; c8 < 8; ++c8) {
+        const int c = 8 * q4 + c8;                       // the contracted channel
+        const size_t widx = CONJ ? ((size_t)row * C + c) * M + 4 * m4 : ((size_t)c * C + row) * M + 4 * m4;
+        const float4 vr = *reinterpret_cast<const float4*>(wr + widx);
+        const float4 vi = *reinterpret_cast<const float4*>(wi + widx);
+        float xr[4], xi[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = 4 * m4 + j;
+            xr[j] = CONJ ? in[c * KP + m] : s_sum(in, c * KP + m);
+            xi[j] = CONJ ? in[c * KP + M + m] : s_sum(in, c * KP + M + m);
+        }
+        const float wrv[4] = {vr.x, vr.y, vr.z, vr.w}, wiv[4] = {vi.x, vi.y, vi.z, vi.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (CONJ) {
+                yr[j] = fmaf(xr[j], wrv[j], fmaf(xi[j], wiv[j], yr[j]));
+                yi[j] = fmaf(xi[j], wrv[j], fmaf(-xr[j], wiv[j], yi[j]));
+            } else {
+                yr[j] = fmaf(xr[j], wrv[j], fmaf(-xi[j], wiv[j], yr[j]));
+                yi[j] = fmaf(xr[j], wiv[j], fmaf(xi[j], wrv[j], yi[j]));
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        yr[j] += __shfl_xor(yr[j], 1, 64);
+        yi[j] += __shfl_xor(yi[j], 1, 64);
+        yr[j] += __shfl_xor(yr[j], 2, 64);
+        yi[j] += __shfl_xor(yi[j], 2, 64);
+    }
+    if (q4 == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = 4 * m4 + j;
+            const float s = m == 0 ? s0 : s1;
+            out[row * KP + m] = s * yr[j];
+            out[row * KP + M + m] = s * yi[j];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------------------------
@@ -201,19 +266,24 @@ __global__ void __launch_bounds__(TPB) fno_forward_kernel(const FwdArgs a) {
     const float* u = a.u.row(t, b);
     const float* act = a.act.row(t, b);
 
+    STAMP(0);
     build_cos(L.ctab, N);
     lift_into(L.xs, u, act, a.w, N, NP);
     __syncthreads();
+    STAMP(1);
     build_table(L.tb, L.ctab, N, NP);
     __syncthreads();
+    STAMP(2);
 
     const float s0 = 1.0f / (float)N, s1 = 2.0f / (float)N;
     for (int l = 0; l < LAYERS; ++l) {
         // ---- A: truncated DFT of the layer input; the pointwise weights ride along -----------------------------
+        STAMP(3 + 4 * l);
         contract_n(L.xs, L.tb, L.S, N, NP);
         load_mat(L.wps, a.w.pw[l]);
         if (threadIdx.x < C) L.misc[threadIdx.x] = a.w.pb[l][threadIdx.x];
         __syncthreads();
+        STAMP(4 + 4 * l);
         // ---- B: spectrum out (for the weight gradient), complex mode mixing -------------------------------------
         if (SAVE) {
             for (int i = threadIdx.x; i < C * K2; i += blockDim.x) {
@@ -221,23 +291,9 @@ __global__ void __launch_bounds__(TPB) fno_forward_kernel(const FwdArgs a) {
                 a.xspec[(((size_t)l * K2 + k) * a.spec_pairs + a.spec_pair0 + p) * C + c] = s_sum(L.S, c * KP + k);
             }
         }
-        for (int e = threadIdx.x; e < C * M; e += blockDim.x) {
-            const int o = e >> 4, m = e & 15;
-            const float* wr = a.w.wr[l] + e;
-            const float* wi = a.w.wi[l] + e;
-            float yr = 0.0f, yi = 0.0f;
-#pragma unroll 8
-            for (int i = 0; i < C; ++i) {
-                const float xr = s_sum(L.S, i * KP + m), xi = s_sum(L.S, i * KP + M + m);
-                const float vr = wr[i * C * M], vi = wi[i * C * M];
-                yr = fmaf(xr, vr, fmaf(-xi, vi, yr));
-                yi = fmaf(xr, vi, fmaf(xi, vr, yi));
-            }
-            const float s = m == 0 ? s0 : s1;
-            L.Z[o * KP + m] = s * yr;
-            L.Z[o * KP + M + m] = s * yi;
-        }
+        mix_modes<false>(a.w.wr[l], a.w.wi[l], L.S, L.Z, s0, s1);
         __syncthreads();
+        STAMP(5 + 4 * l);
         // ---- C: pre = iDFT(Z) + Wp x + b, position tile by position tile, in place ------------------------------
         float* pre_out = SAVE ? a.pre + ((size_t)p * LAYERS + l) * C * N : nullptr;
         for (int ct = wave; ct < (N >> 4); ct += nwaves) {
@@ -266,9 +322,11 @@ __global__ void __launch_bounds__(TPB) fno_forward_kernel(const FwdArgs a) {
                 }
         }
         __syncthreads();
+        STAMP(6 + 4 * l);
     }
 
     // ---- project: delta = p2 . gelu(p1 h + b1) + b2;  out = u + cscale * delta + cshift ---------------------------
+    STAMP(19);
     load_mat(L.wps, a.w.p1_w);
     if (threadIdx.x < C) {
         L.misc[threadIdx.x] = a.w.p1_b[threadIdx.x];
@@ -300,6 +358,7 @@ __global__ void __launch_bounds__(TPB) fno_forward_kernel(const FwdArgs a) {
             if (a.out) a.out[(size_t)p * N + pos] = fmaf(a.cscale, d, u[pos]) + a.cshift;
         }
     }
+    STAMP(20);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -486,21 +545,7 @@ __global__ void __launch_bounds__(TPB) fno_backward_kernel(const BwdArgs a) {
         }
         __syncthreads();
         // ---- GX[i][m] = sum_o G[o][m] conj(W[i][o][m])  -> S[0] ----------------------------------------------------
-        for (int e = threadIdx.x; e < C * M; e += blockDim.x) {
-            const int i = e >> 4, m = e & 15;
-            const float* wr = a.w.wr[l] + (size_t)i * C * M + m;
-            const float* wi = a.w.wi[l] + (size_t)i * C * M + m;
-            float gr = 0.0f, gi = 0.0f;
-#pragma unroll 8
-            for (int o = 0; o < C; ++o) {
-                const float yr = L.Z[o * KP + m], yi = L.Z[o * KP + M + m];
-                const float vr = wr[o * M], vi = wi[o * M];
-                gr = fmaf(yr, vr, fmaf(yi, vi, gr));
-                gi = fmaf(yi, vr, fmaf(-yr, vi, gi));
-            }
-            L.S[i * KP + m] = gr;
-            L.S[i * KP + M + m] = gi;
-        }
+        mix_modes<true>(a.w.wr[l], a.w.wi[l], L.Z, L.S, 1.0f, 1.0f);
         __syncthreads();
         // ---- dx = iDFT(GX) + Wp^T d_pre, in place (position-tile local) ------------------------------------------
         for (int ct = wave; ct < (N >> 4); ct += nwaves) {
@@ -551,20 +596,31 @@ __global__ void __launch_bounds__(TPB) fno_backward_kernel(const BwdArgs a) {
     }
 }
 
-// out[j] = sum_p rows[p][j]   (fixed order: deterministic)
-__global__ void fno_reduce_rows_kernel(const float* rows, int pairs, int width, float* out) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= width) return;
+// out[j] = sum_p rows[p][j]   (fixed order: deterministic).  Block = 64 columns x 8 row groups: the sum over pairs is a
+// latency chain, so it is cut into 8 interleaved chains per column that meet in LDS.
+__global__ void __launch_bounds__(512) fno_reduce_rows_kernel(const float* rows, int pairs, int width, float* out) {
+    __shared__ float part[8][64];
+    const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + col;
     float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-    int p = 0;
-    for (; p + 4 <= pairs; p += 4) {
-        s0 += rows[(size_t)p * width + j];
-        s1 += rows[(size_t)(p + 1) * width + j];
-        s2 += rows[(size_t)(p + 2) * width + j];
-        s3 += rows[(size_t)(p + 3) * width + j];
+    if (j < width) {
+        int p = grp;
+        for (; p + 24 < pairs; p += 32) {
+            s0 += rows[(size_t)p * width + j];
+            s1 += rows[(size_t)(p + 8) * width + j];
+            s2 += rows[(size_t)(p + 16) * width + j];
+            s3 += rows[(size_t)(p + 24) * width + j];
+        }
+        for (; p < pairs; p += 8) s0 += rows[(size_t)p * width + j];
     }
-    for (; p < pairs; ++p) s0 += rows[(size_t)p * width + j];
-    out[j] = (s0 + s1) + (s2 + s3);
+    part[grp][col] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (grp == 0 && j < width) {
+        float v = part[0][col];
+#pragma unroll
+        for (int g = 1; g < 8; ++g) v += part[g][col];
+        out[j] = v;
+    }
 }
 
 // Spectral weight gradient of every layer from the saved spectra (layout [4][32 k][pairs][32 c]):
@@ -587,7 +643,8 @@ __global__ void __launch_bounds__(256) fno_spec_wgrad_kernel(const float* xspec,
     const float* gi = gspec + ((size_t)l * K2 + M + m) * plane;
     f32x4 rr = {0.f, 0.f, 0.f, 0.f}, ii = {0.f, 0.f, 0.f, 0.f}, ir = {0.f, 0.f, 0.f, 0.f}, ri = {0.f, 0.f, 0.f, 0.f};
     const int pairs4 = pairs & ~3;
-    for (int p0 = 0; p0 < pairs4; p0 += 4) {
+#pragma unroll 4
+    for (int p0 = 0; p0 < pairs4; p0 += 4) {   // a latency chain of 4-byte gathers: 16 of them in flight per lane
         const size_t row = (size_t)(p0 + q) * C;
         const float axr = xr[row + 16 * rt + r], axi = xi[row + 16 * rt + r];     // A[row i][k p] = X[p][i]
         const float bgr = gr[row + 16 * ct + r], bgi = gi[row + 16 * ct + r];     // B[k p][col o] = G[p][o]
@@ -723,7 +780,7 @@ int fno_backward(void* stream, const fno_weights* w, int width, int modes, int l
 
 int fno_reduce_rows(void* stream, const float* rows, int pairs, float* out) {
     if (!rows || !out || pairs <= 0) return fail(-1, "fno_reduce_rows: bad argument");
-    hipLaunchKernelGGL(fno_reduce_rows_kernel, dim3((ROW + 255) / 256), dim3(256), 0, (hipStream_t)stream, rows, pairs, ROW, out);
+    hipLaunchKernelGGL(fno_reduce_rows_kernel, dim3((ROW + 63) / 64), dim3(512), 0, (hipStream_t)stream, rows, pairs, ROW, out);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(-2, "fno_reduce_rows launch failed: %s", hipGetErrorString(e));
     return 0;
@@ -744,5 +801,11 @@ int fno_spec_wgrad(void* stream, const float* xspec, const float* gspec, int pai
 }
 
 const char* fno_last_error(void) { return g_err; }
+
+#ifdef FNO_STAMP
+int fno_read_stamps(unsigned long long* host, int n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * (n < 256 ? n : 256)) == hipSuccess ? 0 : -2;
+}
+#endif
 
 }  // extern "C"

@@ -46,4 +46,13 @@ else:
     for _ in range(5):
         one()
     torch.cuda.synchronize()
-    print("ms/step", (time.perf_counter() - t0) / 5 * 1e3)
+    print("eager ms/step", (time.perf_counter() - t0) / 5 * 1e3)
+    if "graph" in sys.argv:      # the same step captured as one hipGraph (PDETrainingModule.fused_step)
+        for _ in range(3):
+            mod.fused_step(batch)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            mod.fused_step(batch)
+        torch.cuda.synchronize()
+        print("graphed ms/step", (time.perf_counter() - t0) / 20 * 1e3)
