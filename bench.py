@@ -365,7 +365,7 @@ def burgers_roofline(E, N, cfg_steps, ms):
 def burgers_fno_leg(dev, steps=30, warmup=5):
     """BASELINE configs[4] (second PDE path; the reference ships neither a Burgers env nor an FNO, so nothing here has a
     reference-side pin beyond the discretisation, tests/test_burgers.py): the fp32 Burgers stepper at 512 grid points and
-    one eager TBPTT training step of the FNO-style surrogate on the fused spectral-convolution kernel."""
+    the TBPTT training step of the FNO-style surrogate on the whole-network kernels (eager, and captured as one hipGraph)."""
     from pdegym.burgers import make_vec
     E, N = 8192, 512
     env = make_vec(E, config=dict(N=N), device=dev.index or 0)
@@ -411,7 +411,8 @@ def burgers_fno_leg(dev, steps=30, warmup=5):
     dt = (time.perf_counter() - t0) / 10
     out["fno_tbptt"] = {"value": 64 / dt, "unit": "seqs/s", "ms_per_step": dt * 1e3,
                         "config": {"factory": "BurgersFNO", "width": 32, "modes": 16, "layers": 4, "B": 64, "T": 20, "N": N},
-                        "path": "eager; spectral convolutions on the fused truncated-DFT HIP kernel, pointwise GEMMs on rocBLAS"}
+                        "path": "eager; whole-network HIP kernels (csrc/fno.hip): one launch per model evaluation and direction, one "
+                                "autograd node per TBPTT chunk"}
     try:   # the same step captured as one hipGraph (PDETrainingModule.fused_step is architecture-agnostic)
         mod.fused_step(batch)
         for _ in range(2):
