@@ -1319,11 +1319,16 @@ __device__ void decoder_forward(const sur_chunk_params& p, const StepLayout& L, 
 }
 
 // decoder backward on LDS-resident activations: L.gA holds d loss / d d on entry, L.dh the gradient wrt hnew on exit.
-// LDS is what limits the (step, sample)-parallel kernel to one workgroup per CU at N = 256, so nothing is allocated
-// that a dead buffer can serve: the LayerNorm backward's normalised-activation scratch lives in the post-LayerNorm
-// activation that was consumed just before (a2 for the last norm, a1 -- dead after the 7-tap weight gradient -- for the
-// other two), and L.dh may alias L.gB (free once the first norm's backward has read it).
-__device__ void decoder_backward(const sur_chunk_params& p, const StepLayout& L, const float* const* w, float* const* g) {
+// LDS is what limits the (step, sample)-parallel kernel's residency at N = 256, so nothing is allocated that a dead buffer
+// can serve (dec_bwd_kernel lays the buffers out): the LayerNorm backward's normalised-activation scratch lives in the
+// post-LayerNorm activation that was consumed just before (a2 for the last norm, a1 -- dead after the 7-tap weight
+// gradient -- for the other two), L.dh aliases L.gB, and two activations arrive LATE from registers: p0 into p1's
+// buffer once the middle norm's backward has read p1 (`late_p0`), h into a0's buffer once the second transposed
+// convolution's weight gradient has read a0 (`late_h`).  Each is stored right after a barrier that retires the old
+// contents and at least one barrier before its first reader.
+template <typename StoreP0, typename StoreH>
+__device__ void decoder_backward(const sur_chunk_params& p, const StepLayout& L, const float* const* w, float* const* g,
+                                 StoreP0 late_p0, StoreH late_h) {
     const int n = L.n;
     conv_bwd_weight<5>(L.gA, 1, L.a2, 1, n, 1, 2, g[SUR_ST_CV3_W], g[SUR_ST_CV3_B], all_waves(), false);
     STAMP(12);
@@ -1337,10 +1342,12 @@ __device__ void decoder_backward(const sur_chunk_params& p, const StepLayout& L,
     STAMP(16);
     act_ln_bwd(L.gB, L.p1, p.c_mid, n, w[SUR_ST_LN1_W], true, L.gA, L.a1, g[SUR_ST_LN1_W], g[SUR_ST_LN1_B]);
     STAMP(17);
+    late_p0();      // p1 is dead (act_ln_bwd ends with a barrier); first reader: the act_ln_bwd two barriers below
     deconv_bwd_weight(L.gA, p.c_mid, L.a0, p.cs, 2 * p.hq, g[SUR_ST_DC1_W], g[SUR_ST_DC1_B], lower_half(), false);
     STAMP(18);
     deconv_bwd_data(L.gA, p.c_mid, 2 * p.hq, w[SUR_ST_DC1_W], p.cs, L.gB, upper_half(), true);
     STAMP(19);
+    late_h();       // a0 is dead; first reader: deconv_bwd_weight below, behind act_ln_bwd's barrier
     act_ln_bwd(L.gB, L.p0, p.cs, 2 * p.hq, w[SUR_ST_LN0_W], true, L.gA, L.a1, g[SUR_ST_LN0_W], g[SUR_ST_LN0_B]);
     STAMP(26);
     deconv_bwd_weight(L.gA, p.cs, L.hnew, p.cs, p.hq, g[SUR_ST_DC0_W], g[SUR_ST_DC0_B], lower_half(), false);
@@ -1464,7 +1471,8 @@ __host__ __device__ inline int cell_wgrad_act_floats(const sur_chunk_params& p) 
 }
 __host__ __device__ inline int dec_act_floats(const sur_chunk_params& p, bool backward) {
     const int s = p.cs * p.hq, n = 4 * p.hq;
-    if (backward) return s + dec_part_floats(p) + 2 * step_max_act(p);   // hnew, p0..a2, gA, gB (dh aliases gB)
+    // backward (dec_bwd_kernel): three activation buffers [a0 -> h | p1 -> p0 | a1], gA, gB (dh, and p2 / a2 in its tail)
+    if (backward) return 5 * step_max_act(p);
     return s + dec_part_floats(p) + n;                                    // hnew, p0..a2, d
 }
 
@@ -1697,24 +1705,38 @@ dgrad_scan_kernel(const float* __restrict__ dd_all, const float* __restrict__ do
 }
 
 // decoder backward of every (step, sample) pair: dh_dec[m] = d loss / d h_m through the decoder; decoder parameter
-// gradients into this workgroup's partial row.  Built for two workgroups per CU.
-__global__ void __launch_bounds__(TPB, PAR_OCC)
+// gradients into this workgroup's partial row.  Built for DEC_BWD_OCC workgroups per CU: at N = 256 the LDS layout below
+// is 52 KB (round 2: 75 KB, two per CU), so three workgroups share a CU and the 640 pairs of a 10-step chunk are ONE round
+// of workgroups.  Saved block of a pair: [gates 4s | c s | h s | p0 | a0 | p1 | a1 | p2 | a2].
+//   LDS: X2 = a0 (later h) | X1 = p1 (later p0) | X0 = a1 | gA | gB (dh; p2, a2 in its last 2n floats: phase 1 only uses
+//        the first n floats of gB, and p2 / a2 are dead when the 7-tap data gradient fills it)
+// p0 and h wait in registers (2 + 1 float4 per thread at N = 256) until their buffers are free (decoder_backward).
+#ifndef DEC_BWD_OCC
+#define DEC_BWD_OCC 3
+#endif
+constexpr int DEC_LATE_P0 = 2;   // float4 registers per thread for the late p0: cs * 2 hq <= 2 * 4 * TPB
+constexpr int DEC_LATE_H = 1;    //                                  ... for the late h:  cs * hq <= 4 * TPB
+__global__ void __launch_bounds__(TPB, DEC_BWD_OCC)
 dec_bwd_kernel(const sur_chunk_params p, const float* __restrict__ saved, const float* __restrict__ ga_all, int M,
                float* __restrict__ dh_dec, int grads_in_lds, int row_base) {
     extern __shared__ __align__(16) float lds[];
     const int s = p.cs * p.hq, n = 4 * p.hq, mx = step_max_act(p);
+    const int a0f = p.cs * 2 * p.hq, a1f = p.c_mid * n;
     StepLayout L{};
     L.n = n;
-    L.hnew = lds;
-    L.p0 = L.hnew + s;
-    L.a0 = L.p0 + p.cs * 2 * p.hq;
-    L.p1 = L.a0 + p.cs * 2 * p.hq;
-    L.a1 = L.p1 + p.c_mid * n;
-    L.p2 = L.a1 + p.c_mid * n;
-    L.a2 = L.p2 + n;
-    L.gA = L.a2 + n;
+    float* X2 = lds;
+    float* X1 = X2 + mx;
+    float* X0 = X1 + mx;
+    L.a0 = X2;
+    L.hnew = X2;
+    L.p1 = X1;
+    L.p0 = X1;
+    L.a1 = X0;
+    L.gA = X0 + mx;
     L.gB = L.gA + mx;
     L.dh = L.gB;              // s <= mx: the first LayerNorm's backward has consumed gB before dh is written
+    L.p2 = L.gB + mx - 2 * n;
+    L.a2 = L.p2 + n;
     float* wbase = L.gB + mx;
     const float* w[SUR_ST_NPARAM];
     stage_range<ST_NDEC>(p, ST_NLSTM, wbase, w);
@@ -1736,11 +1758,42 @@ dec_bwd_kernel(const sur_chunk_params p, const float* __restrict__ saved, const 
     }
     __syncthreads();
     const size_t save_stride = step_saved_floats(p);
-    const int nload4 = (s + dec_part_floats(p)) >> 2;   // [h_k | p0 .. a2] is contiguous in the saved block
     for (int m = blockIdx.x; m < M; m += gridDim.x) {
+        const float* blk = saved + (size_t)m * save_stride + 5 * s;        // [h | p0 | a0 | p1 | a1 | p2 | a2]
+        // the late activations start their trip now and land in registers
+        float4 rp0[DEC_LATE_P0], rh[DEC_LATE_H];
+#pragma unroll
+        for (int u = 0; u < DEC_LATE_P0; ++u) {
+            const int i = threadIdx.x + u * TPB;
+            rp0[u] = i < (a0f >> 2) ? reinterpret_cast<const float4*>(blk + s)[i] : float4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < DEC_LATE_H; ++u) {
+            const int i = threadIdx.x + u * TPB;
+            rh[u] = i < (s >> 2) ? reinterpret_cast<const float4*>(blk)[i] : float4{0.f, 0.f, 0.f, 0.f};
+        }
         for (int i = threadIdx.x; i < n; i += blockDim.x) L.gA[i] = ga_all[(size_t)m * n + i];
-        lds_load_v4(L.hnew, saved + (size_t)m * save_stride + 5 * s, nload4);
-        decoder_backward(p, L, w, g);
+        for (int i = threadIdx.x; i < (2 * n) >> 2; i += blockDim.x)
+            reinterpret_cast<float4*>(L.p2)[i] = reinterpret_cast<const float4*>(blk + s + 2 * a0f + 2 * a1f)[i];
+        for (int i = threadIdx.x; i < (a0f >> 2); i += blockDim.x)
+            reinterpret_cast<float4*>(X2)[i] = reinterpret_cast<const float4*>(blk + s + a0f)[i];
+        lds_load_v4(X1, blk + s + 2 * a0f, a1f >> 2);                      // p1 (ends with a barrier)
+        lds_load_v4(X0, blk + s + 2 * a0f + a1f, a1f >> 2);                // a1
+        decoder_backward(p, L, w, g,
+                         [&] {
+#pragma unroll
+                             for (int u = 0; u < DEC_LATE_P0; ++u) {
+                                 const int i = threadIdx.x + u * TPB;
+                                 if (i < (a0f >> 2)) reinterpret_cast<float4*>(X1)[i] = rp0[u];
+                             }
+                         },
+                         [&] {
+#pragma unroll
+                             for (int u = 0; u < DEC_LATE_H; ++u) {
+                                 const int i = threadIdx.x + u * TPB;
+                                 if (i < (s >> 2)) reinterpret_cast<float4*>(X2)[i] = rh[u];
+                             }
+                         });
         for (int i = threadIdx.x; i < s; i += blockDim.x) dh_dec[(size_t)m * s + i] = L.dh[i];
         __syncthreads();
     }
@@ -2430,9 +2483,12 @@ int sur_chunk_saved_floats(const sur_chunk_params* p) {
     if (!p) return 0;
     // the GEMM tiles want whole 16-wide latent rows; the cell backward moves [gates | c] in whole 1 KiB DMA pieces
     if ((p->hq & 15) || ((p->ca * p->hq) & 3) || (5 * p->cs * p->hq) % DMA_PIECE || p->cs * p->hq > CELL_EPT * TPB) return 0;
-    // the decoder backward keeps its LayerNorm scratch in dead activation buffers (decoder_backward): a1 (+ p2, a2 behind it)
-    // must hold a [cs][2 hq] tile, and dh [cs][hq] must fit the gradient ping-pong buffer
-    if (p->cs * 2 * p->hq > p->c_mid * 4 * p->hq + 8 * p->hq || p->cs * p->hq > step_max_act(*p)) return 0;
+    // the decoder backward (dec_bwd_kernel) keeps every activation in buffers of step_max_act floats, p2 / a2 in the tail of
+    // the gradient ping-pong buffer behind the first n floats its first phase uses, and two late activations in
+    // DEC_LATE_P0 / DEC_LATE_H float4 registers per thread
+    if (p->cs * p->hq > step_max_act(*p) || 12 * p->hq > step_max_act(*p) || p->cs * 2 * p->hq > 4 * DEC_LATE_P0 * TPB ||
+        p->cs * p->hq > 4 * DEC_LATE_H * TPB)
+        return 0;
     return step_saved_floats(*p);
 }
 

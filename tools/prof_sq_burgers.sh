@@ -30,5 +30,8 @@ for name, d in s.get("kernels", {}).items():
                  "valu_instructions_per_point_substep": m["SQ_INSTS_VALU"] * 64.0 / (E * N * cfg) if "SQ_INSTS_VALU" in m else None,
                  "kernel_source_sha": sha}
 json.dump(res, open(os.path.join(root, "profiles", "burgers_sq_counters.json"), "w"), indent=1)
+# gpurun merges only gpurun_out/ back: leave a copy there to be carried into profiles/ by hand
+os.makedirs(os.path.join(root, "gpurun_out", "profiles_out"), exist_ok=True)
+json.dump(res, open(os.path.join(root, "gpurun_out", "profiles_out", "burgers_sq_counters.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY

@@ -27,6 +27,10 @@ def merge(path, entry):
         data = {}
     data[key] = entry
     json.dump(data, open(path, "w"), indent=1)
+    # gpurun merges only gpurun_out/ back: leave a copy there to be carried into profiles/ by hand
+    out = os.path.join(ROOT, "gpurun_out", "profiles_out")
+    os.makedirs(out, exist_ok=True)
+    json.dump(data, open(os.path.join(out, os.path.basename(path)), "w"), indent=1)
 
 
 pmc = os.path.join(ROOT, "gpurun_out", f"pmc_{tag}", "summary.json")
