@@ -128,6 +128,38 @@ def cpu_baseline(E, N, L, target_seconds=12.0):
         out["reference_call_structure"] = reference_structure_baseline(N, L)
     except Exception as exc:  # scipy / torch CPU missing must not lose the baseline
         out["reference_call_structure"] = {"error": f"{type(exc).__name__}: {exc}"}
+    try:
+        out["cpu_twin"] = cpu_twin_baseline(E, N, L, cores)
+    except Exception as exc:
+        out["cpu_twin"] = {"error": f"{type(exc).__name__}: {exc}"}
+    return out
+
+
+def cpu_twin_baseline(E, N, L, cores, seconds=4.0):
+    """SURVEY 8(d) baseline (B): the product's own CPU twin behind the C ABI (device = -1, csrc/ks_cpu.cpp: vectorised C++,
+    envs over host threads), fast arithmetic like the GPU number, all cores and one thread.  Product code, not the oracle."""
+    import kspde
+    u0 = np.random.RandomState(1234).uniform(-0.4, 0.4, (E, N))
+    act = np.random.RandomState(99).uniform(-1, 1, (E, 4)).astype(np.float32)
+    out = {"unit": "sub-steps/s", "what": "libkspde CPU twin (device = -1), fast mode, ks_step_actions on this workload"}
+    for label, threads, envs in (("all_cores", cores, E), ("one_thread", 1, max(1, E // max(cores, 1)))):
+        os.environ["KSPDE_CPU_THREADS"] = str(threads)
+        try:
+            s = kspde.KSStepper(envs, N, L, DT, device=-1, mode="fast")
+            s.set_forcing(forcing_matrix(L, N))
+            s.set_state(u0[:envs])
+            s.step_actions(act[:envs], 25, want_obs=False)
+            t0 = time.perf_counter()
+            s.step_actions(act[:envs], 50, want_obs=False)
+            probe = time.perf_counter() - t0
+            nsub = int(max(50, min(CFG_STEPS * 40, 50 * seconds / max(probe, 1e-6))))
+            t0 = time.perf_counter()
+            s.step_actions(act[:envs], nsub, want_obs=False)
+            dt = time.perf_counter() - t0
+            out[label] = {"value": envs * nsub / dt, "threads": threads, "envs": envs, "sub_steps": nsub, "seconds": dt}
+            s.close()
+        finally:
+            os.environ.pop("KSPDE_CPU_THREADS", None)
     return out
 
 
