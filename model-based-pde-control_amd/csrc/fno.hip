@@ -25,6 +25,9 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <map>
+#include <mutex>
+#include <utility>
 
 #include "../../include/spectral_hip.h"
 
@@ -76,6 +79,7 @@ struct FwdArgs {
     float* out;             // [pairs][N]  u + cscale * delta + cshift, or nullptr
     float* pre;             // [pairs][4][32][N] saved pre-activations, or nullptr (inference)
     float* xspec;           // [4][32 k][spec_pairs][32 c] truncated spectra of the layer inputs, or nullptr
+    const float* tabg;      // [32][N] twiddle matrix (global, per device and N)
     int n, nb, pairs;
     int spec_pairs, spec_pair0;   // the spectra buffer spans spec_pairs pairs; this launch's pair p is its pair spec_pair0 + p
     float cscale, cshift;
@@ -91,6 +95,7 @@ struct BwdArgs {
     float* gspec;           // [4][32 k][spec_pairs][32 c] scaled spectra of d_pre
     float* rows;            // [pairs][ROW] parameter-gradient rows (everything but the spectral weights)
     float* dbase;           // [pairs][N] d loss / d u (including gout passed through), or nullptr
+    const float* tabg;      // [32][N] twiddle matrix (global, per device and N)
     int n, nb, pairs;
     int spec_pairs, spec_pair0;
     float cscale;
@@ -101,10 +106,30 @@ constexpr int R_LIFT_W = 0, R_LIFT_B = 64, R_LAYER = 96, R_LAYER_SZ = 1024 + 32;
 constexpr int R_P1W = R_LAYER + LAYERS * R_LAYER_SZ, R_P1B = R_P1W + 1024, R_P2W = R_P1B + 32, R_P2B = R_P2W + 32;
 constexpr int ROW = ((R_P2B + 1 + 63) / 64) * 64;
 
-__device__ __forceinline__ float gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// GELU (exact, erf form) and its derivative from ONE exponential: with z = |x| / sqrt(2), erf(z) by Abramowitz & Stegun
+// 7.1.26 (|error| <= 1.5e-7, at fp32 resolution) needs exp(-z^2) = exp(-x^2 / 2), which is also the Gaussian of gelu'.
+// ~14 VALU instructions against ~40 of erff() -- the activation epilogues were a third of the forward kernel.
+__device__ __forceinline__ void gelu_parts(float x, float& cdf, float& pdf) {
+    const float ax = fabsf(x);
+    const float e = __expf(-0.5f * x * x);
+    const float t = __frcp_rn(fmaf(0.3275911f * 0.70710678118654752f, ax, 1.0f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float erf_abs = fmaf(-poly * t, e, 1.0f);            // erf(|x| / sqrt 2)
+    cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
+    pdf = 0.3989422804014327f * e;
+}
+__device__ __forceinline__ float gelu(float x) {
+    float cdf, pdf;
+    gelu_parts(x, cdf, pdf);
+    return x * cdf;
+}
 __device__ __forceinline__ float gelu_grad(float x) {
-    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-    return fmaf(x * 0.3989422804014327f, __expf(-0.5f * x * x), cdf);
+    float cdf, pdf;
+    gelu_parts(x, cdf, pdf);
+    return fmaf(x, pdf, cdf);
 }
 
 // diagnostic build (-DFNO_STAMP, tools/fno_stamp_run.py): shader-clock stamps of workgroup 0 at the phase boundaries
@@ -119,7 +144,7 @@ __device__ unsigned long long g_stamps[256];
 #endif
 
 struct Lds {
-    float *xs, *tb, *S, *Z, *wps, *gv, *ctab, *misc;
+    float *xs, *tb, *S, *Z, *wps, *gv, *misc;
     int NP;
     __device__ Lds(float* base, int N) {
         NP = N + 4;
@@ -129,25 +154,31 @@ struct Lds {
         Z = S + KS * C * KP;       // [32][KP]
         wps = Z + C * KP;          // [32][KP]
         gv = wps + C * KP;         // [N]
-        ctab = gv + N;             // [N]
-        misc = ctab + N;           // [256]
+        misc = gv + N;             // [256]
     }
-    static size_t floats(int N) { return 2 * (size_t)C * (N + 4) + (KS + 2) * C * KP + 2 * (size_t)N + 256; }
+    static size_t floats(int N) { return 2 * (size_t)C * (N + 4) + (KS + 2) * C * KP + (size_t)N + 256; }
 };
 
-// ctab[k] = cos(2 pi k / N)
-__device__ __forceinline__ void build_cos(float* ctab, int N) {
-    for (int k = threadIdx.x; k < N; k += blockDim.x) ctab[k] = cospif(2.0f * (float)k / (float)N);
-}
 // tab[k][n], k < 2M: k < M -> cos(2 pi k n / N), else -sin(2 pi (k - M) n / N).  One matrix serves the forward DFT
 // (B[n][k]) and the inverse (B[k][n]); rows padded like the activations, so both gathers are bank-conflict free.
-__device__ __forceinline__ void build_table(float* tab, const float* ctab, int N, int NP) {
-    const int nmask = N - 1, quarter = N >> 2, sh = __ffs(N) - 1;
-    for (int i = threadIdx.x; i < K2 * N; i += blockDim.x) {
-        const int k = i >> sh, n = i & nmask;
-        const bool is_sin = k >= M;
-        const int idx = ((is_sin ? k - M : k) * n) & nmask;
-        tab[k * NP + n] = is_sin ? -ctab[(idx - quarter) & nmask] : ctab[idx];
+// The matrix is computed ONCE per (device, N) into global memory (twiddle_init_kernel, host cache below) and copied into
+// LDS with 16-byte loads: rebuilding it from a cosine table cost 8 k of a forward evaluation's 165 k clocks, and the
+// backward pass needs it four times per evaluation (its buffer doubles as the layer-input buffer).
+__global__ void twiddle_init_kernel(float* tab, int N) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= K2 * N) return;
+    const int k = i / N, n = i - k * N;
+    const bool is_sin = k >= M;
+    const int mode = is_sin ? k - M : k;
+    const int idx = (int)(((long)mode * n) % N);          // exact argument reduction in integers
+    const float ang = 2.0f * (float)idx / (float)N;       // in units of pi
+    tab[i] = is_sin ? -sinpif(ang) : cospif(ang);
+}
+__device__ __forceinline__ void load_table(float* tab, const float* __restrict__ tabg, int N, int NP) {
+    const int sh = __ffs(N) - 1;
+    for (int i = threadIdx.x; i < (K2 * N) >> 2; i += blockDim.x) {
+        const int e = i << 2, k = e >> sh, n = e & (N - 1);
+        *reinterpret_cast<float4*>(tab + k * NP + n) = reinterpret_cast<const float4*>(tabg)[i];
     }
 }
 
@@ -203,17 +234,28 @@ __device__ __forceinline__ void lift_into(float* xs, const float* u, const float
 //   forward  (CONJ = false): out[o][m] = s_m sum_i in[i][m] W[i][o][m]          in = S (summed over its K-split halves)
 //   backward (CONJ = true) : out[i][m] =     sum_o in[o][m] conj(W[i][o][m])    in = Z (one copy)
 // Spectra rows are [re 0..15 | im 0..15].
+struct MixRegs {
+    float4 vr[8], vi[8];
+};
+// the thread's 16 weight loads (issued BEFORE the contraction that produces the spectrum: L2 latency under MFMA work)
 template <bool CONJ>
-__device__ __forceinline__ void mix_modes(const float* __restrict__ wr, const float* __restrict__ wi, const float* in, float* out,
-                                          float s0, float s1) {
+__device__ __forceinline__ void mix_load(const float* __restrict__ wr, const float* __restrict__ wi, MixRegs& m) {
     const int t = threadIdx.x, q4 = t & 3, m4 = (t >> 2) & 3, row = t >> 4;
-    float yr[4] = {0.f, 0.f, 0.f, 0.f}, yi[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int c8 = 0; c8 < 8; ++c8) {
         const int c = 8 * q4 + c8;                       // the contracted channel
         const size_t widx = CONJ ? ((size_t)row * C + c) * M + 4 * m4 : ((size_t)c * C + row) * M + 4 * m4;
-        const float4 vr = *reinterpret_cast<const float4*>(wr + widx);
-        const float4 vi = *reinterpret_cast<const float4*>(wi + widx);
+        m.vr[c8] = *reinterpret_cast<const float4*>(wr + widx);
+        m.vi[c8] = *reinterpret_cast<const float4*>(wi + widx);
+    }
+}
+template <bool CONJ>
+__device__ __forceinline__ void mix_compute(const MixRegs& w, const float* in, float* out, float s0, float s1) {
+    const int t = threadIdx.x, q4 = t & 3, m4 = (t >> 2) & 3, row = t >> 4;
+    float yr[4] = {0.f, 0.f, 0.f, 0.f}, yi[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c8 = 0; c8 < 8; ++c8) {
+        const int c = 8 * q4 + c8;
         float xr[4], xi[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -221,7 +263,8 @@ __device__ __forceinline__ void mix_modes(const float* __restrict__ wr, const fl
             xr[j] = CONJ ? in[c * KP + m] : s_sum(in, c * KP + m);
             xi[j] = CONJ ? in[c * KP + M + m] : s_sum(in, c * KP + M + m);
         }
-        const float wrv[4] = {vr.x, vr.y, vr.z, vr.w}, wiv[4] = {vi.x, vi.y, vi.z, vi.w};
+        const float wrv[4] = {w.vr[c8].x, w.vr[c8].y, w.vr[c8].z, w.vr[c8].w};
+        const float wiv[4] = {w.vi[c8].x, w.vi[c8].y, w.vi[c8].z, w.vi[c8].w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (CONJ) {
@@ -267,11 +310,9 @@ __global__ void __launch_bounds__(TPB) fno_forward_kernel(const FwdArgs a) {
     const float* act = a.act.row(t, b);
 
     STAMP(0);
-    build_cos(L.ctab, N);
     lift_into(L.xs, u, act, a.w, N, NP);
-    __syncthreads();
     STAMP(1);
-    build_table(L.tb, L.ctab, N, NP);
+    load_table(L.tb, a.tabg, N, NP);
     __syncthreads();
     STAMP(2);
 
@@ -279,6 +320,8 @@ __global__ void __launch_bounds__(TPB) fno_forward_kernel(const FwdArgs a) {
     for (int l = 0; l < LAYERS; ++l) {
         // ---- A: truncated DFT of the layer input; the pointwise weights ride along -----------------------------
         STAMP(3 + 4 * l);
+        MixRegs mw;
+        mix_load<false>(a.w.wr[l], a.w.wi[l], mw);
         contract_n(L.xs, L.tb, L.S, N, NP);
         load_mat(L.wps, a.w.pw[l]);
         if (threadIdx.x < C) L.misc[threadIdx.x] = a.w.pb[l][threadIdx.x];
@@ -291,7 +334,7 @@ __global__ void __launch_bounds__(TPB) fno_forward_kernel(const FwdArgs a) {
                 a.xspec[(((size_t)l * K2 + k) * a.spec_pairs + a.spec_pair0 + p) * C + c] = s_sum(L.S, c * KP + k);
             }
         }
-        mix_modes<false>(a.w.wr[l], a.w.wi[l], L.S, L.Z, s0, s1);
+        mix_compute<false>(mw, L.S, L.Z, s0, s1);
         __syncthreads();
         STAMP(5 + 4 * l);
         // ---- C: pre = iDFT(Z) + Wp x + b, position tile by position tile, in place ------------------------------
@@ -400,7 +443,6 @@ __global__ void __launch_bounds__(TPB) fno_backward_kernel(const BwdArgs a) {
     const bool has_gout = a.gout && t == a.gout_t;
 
     // ---- g = d loss / d delta (+ cscale * d loss / d out);  h = pre_3;  W1, b1, W2 --------------------------------
-    build_cos(L.ctab, N);
     for (int n = threadIdx.x; n < N; n += blockDim.x) {
         float g = a.gdelta[(size_t)p * N + n];
         if (has_gout) g = fmaf(a.cscale, a.gout[(size_t)b * N + n], g);
@@ -532,9 +574,11 @@ __global__ void __launch_bounds__(TPB) fno_backward_kernel(const BwdArgs a) {
         __syncthreads();
         for (int i = threadIdx.x; i < C * C; i += blockDim.x)
             grow[R_LAYER + l * R_LAYER_SZ + i] = s_sum(L.S, (i >> 5) * KP + (i & 31));
-        build_table(L.xs, L.ctab, N, NP);          // x_l is dead: its buffer becomes the twiddle table
+        load_table(L.xs, a.tabg, N, NP);           // x_l is dead: its buffer becomes the twiddle table
         __syncthreads();
         // ---- G = s (.) DFT(d_pre) -------------------------------------------------------------------------------
+        MixRegs mw;
+        mix_load<true>(a.w.wr[l], a.w.wi[l], mw);
         contract_n(db, L.xs, L.S, N, NP);
         __syncthreads();
         for (int i = threadIdx.x; i < C * K2; i += blockDim.x) {
@@ -545,7 +589,7 @@ __global__ void __launch_bounds__(TPB) fno_backward_kernel(const BwdArgs a) {
         }
         __syncthreads();
         // ---- GX[i][m] = sum_o G[o][m] conj(W[i][o][m])  -> S[0] ----------------------------------------------------
-        mix_modes<true>(a.w.wr[l], a.w.wi[l], L.Z, L.S, 1.0f, 1.0f);
+        mix_compute<true>(mw, L.Z, L.S, 1.0f, 1.0f);
         __syncthreads();
         // ---- dx = iDFT(GX) + Wp^T d_pre, in place (position-tile local) ------------------------------------------
         for (int ct = wave; ct < (N >> 4); ct += nwaves) {
@@ -695,6 +739,40 @@ int launch(K kernel, const char* who, void* stream, int pairs, int n, const A& a
     return 0;
 }
 
+// twiddle matrix of (current device, N): created on first use (one tiny kernel + one synchronisation), then shared by every
+// launch.  First use inside a stream capture is refused -- a warm-up call (which any capture needs anyway) creates it.
+std::mutex g_tab_mutex;
+std::map<std::pair<int, int>, float*> g_tabs;
+
+const float* twiddle_table(const char* who, int n, hipStream_t stream, int* rc) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        *rc = fail(-2, "%s: hipGetDevice failed", who);
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lock(g_tab_mutex);
+    auto it = g_tabs.find({dev, n});
+    if (it != g_tabs.end()) return it->second;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &st) == hipSuccess && st != hipStreamCaptureStatusNone) {
+        *rc = fail(-4, "%s: first use for N = %d inside a stream capture (run one eager call first)", who, n);
+        return nullptr;
+    }
+    float* tab = nullptr;
+    if (hipMalloc((void**)&tab, sizeof(float) * K2 * n) != hipSuccess) {
+        *rc = fail(-2, "%s: hipMalloc of the twiddle matrix failed", who);
+        return nullptr;
+    }
+    hipLaunchKernelGGL(twiddle_init_kernel, dim3((K2 * n + 255) / 256), dim3(256), 0, stream, tab, n);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) {
+        (void)hipFree(tab);
+        *rc = fail(-2, "%s: twiddle matrix initialisation failed", who);
+        return nullptr;
+    }
+    g_tabs[{dev, n}] = tab;
+    return tab;
+}
+
 Weights weights_of(const fno_weights* w) {
     Weights o;
     o.lift_w = w->lift_w;
@@ -742,6 +820,9 @@ int fno_forward(void* stream, const fno_weights* w, int width, int modes, int la
     a.xspec = xspec;
     a.spec_pairs = spec_pairs;
     a.spec_pair0 = spec_pair0;
+    int trc = 0;
+    a.tabg = twiddle_table("fno_forward", n, (hipStream_t)stream, &trc);
+    if (!a.tabg) return trc;
     a.n = n;
     a.nb = nb;
     a.pairs = pairs;
@@ -771,6 +852,9 @@ int fno_backward(void* stream, const fno_weights* w, int width, int modes, int l
     a.spec_pair0 = spec_pair0;
     a.rows = rows;
     a.dbase = dbase;
+    int trc = 0;
+    a.tabg = twiddle_table("fno_backward", n, (hipStream_t)stream, &trc);
+    if (!a.tabg) return trc;
     a.n = n;
     a.nb = nb;
     a.pairs = pairs;
