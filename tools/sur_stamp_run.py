@@ -16,8 +16,9 @@ dev = torch.device("cuda", 0)
 ops.enable_fused(True)
 lib = hipops.load()
 lib.sur_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
-m = build_module(dev)
-batch = synthetic_batch(B=64, device=dev)
+N = 256 if "n256" in sys.argv[1:] else 64
+m = build_module(dev, N=N)
+batch = synthetic_batch(B=64, N=N, device=dev)
 def fwd_bwd():
     with hipops.inner_forks(False):   # one kernel at a time: the stamp buffer is shared by every launch
         _fwd_bwd()
@@ -44,7 +45,7 @@ names = {1: "cell fwd: gates GEMM", 2: "cell fwd: gate activations", 3: "dec fwd
          18: "dec bwd: deconv1 weight grad", 19: "dec bwd: deconv1 data grad", 26: "dec bwd: LN0 bwd",
          27: "dec bwd: deconv0 weight grad"}
 vals = list(buf)
-print("one training step (forward + backward), workgroup 0 of every launch, shader-clock cycles summed over the step:")
+print(f"N = {N}: one training step (forward + backward), workgroup 0 of every launch, shader-clock cycles summed over the step:")
 print("(cell phases: 20 executions (2 chunks x 10 steps); decoder phases: the (step, sample) pairs workgroup 0 handles;")
 print(" the first phase of each kernel also contains the time since the previous stamped kernel ended)")
 for i, n in sorted(names.items()):
