@@ -675,47 +675,55 @@ struct WgradOut {
     float* dwi[LAYERS];
 };
 
-__global__ void __launch_bounds__(256) fno_spec_wgrad_kernel(const float* xspec, const float* gspec, int pairs, const WgradOut dst) {
+// 16 waves per workgroup: 4 output tiles x 4 interleaved quarters of the pair axis (the contraction is a latency chain of
+// 4-byte gathers: K = 1 280 pairs at B = 64, T = 20), the quarters meet in LDS.
+constexpr int WG_KS = 4;
+__global__ void __launch_bounds__(256 * WG_KS) fno_spec_wgrad_kernel(const float* xspec, const float* gspec, int pairs, const WgradOut dst) {
+    __shared__ float part[WG_KS][4][2][256];     // [k quarter][tile][re | im][lane * 4 + j]
     const int l = blockIdx.x / M, m = blockIdx.x % M;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tile = wave & 3, ks = wave >> 2;
     const int r = lane & 15, q = lane >> 4;
-    const int rt = wave >> 1, ct = wave & 1;                  // output tile: rows i (16 rt ..), cols o (16 ct ..)
+    const int rt = tile >> 1, ct = tile & 1;                  // output tile: rows i (16 rt ..), cols o (16 ct ..)
     const size_t plane = (size_t)pairs * C;
     const float* xr = xspec + ((size_t)l * K2 + m) * plane;      // [pairs][32 c]
     const float* xi = xspec + ((size_t)l * K2 + M + m) * plane;
     const float* gr = gspec + ((size_t)l * K2 + m) * plane;
     const float* gi = gspec + ((size_t)l * K2 + M + m) * plane;
     f32x4 rr = {0.f, 0.f, 0.f, 0.f}, ii = {0.f, 0.f, 0.f, 0.f}, ir = {0.f, 0.f, 0.f, 0.f}, ri = {0.f, 0.f, 0.f, 0.f};
-    const int pairs4 = pairs & ~3;
-#pragma unroll 4
-    for (int p0 = 0; p0 < pairs4; p0 += 4) {   // a latency chain of 4-byte gathers: 16 of them in flight per lane
-        const size_t row = (size_t)(p0 + q) * C;
-        const float axr = xr[row + 16 * rt + r], axi = xi[row + 16 * rt + r];     // A[row i][k p] = X[p][i]
-        const float bgr = gr[row + 16 * ct + r], bgi = gi[row + 16 * ct + r];     // B[k p][col o] = G[p][o]
-        rr = __builtin_amdgcn_mfma_f32_16x16x4f32(axr, bgr, rr, 0, 0, 0);
-        ii = __builtin_amdgcn_mfma_f32_16x16x4f32(axi, bgi, ii, 0, 0, 0);
-        ir = __builtin_amdgcn_mfma_f32_16x16x4f32(axr, bgi, ir, 0, 0, 0);
-        ri = __builtin_amdgcn_mfma_f32_16x16x4f32(axi, bgr, ri, 0, 0, 0);
-    }
-    if (pairs4 < pairs) {                                     // ragged tail: zero-padded operands
-        const int pp = pairs4 + q;
+    for (int p0 = 4 * ks; p0 < pairs; p0 += 4 * WG_KS) {      // zero-padded operands beyond the last pair
+        const int pp = p0 + q;
         const bool ok = pp < pairs;
         const size_t row = (size_t)(ok ? pp : 0) * C;
-        const float axr = ok ? xr[row + 16 * rt + r] : 0.f, axi = ok ? xi[row + 16 * rt + r] : 0.f;
-        const float bgr = ok ? gr[row + 16 * ct + r] : 0.f, bgi = ok ? gi[row + 16 * ct + r] : 0.f;
+        const float axr = ok ? xr[row + 16 * rt + r] : 0.f, axi = ok ? xi[row + 16 * rt + r] : 0.f;   // A[row i][k p] = X[p][i]
+        const float bgr = ok ? gr[row + 16 * ct + r] : 0.f, bgi = ok ? gi[row + 16 * ct + r] : 0.f;   // B[k p][col o] = G[p][o]
         rr = __builtin_amdgcn_mfma_f32_16x16x4f32(axr, bgr, rr, 0, 0, 0);
         ii = __builtin_amdgcn_mfma_f32_16x16x4f32(axi, bgi, ii, 0, 0, 0);
         ir = __builtin_amdgcn_mfma_f32_16x16x4f32(axr, bgi, ir, 0, 0, 0);
         ri = __builtin_amdgcn_mfma_f32_16x16x4f32(axi, bgr, ri, 0, 0, 0);
     }
-    float* outr = dst.dwr[l];
-    float* outi = dst.dwi[l];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int i = 16 * rt + 4 * q + j, o = 16 * ct + r;
-        const size_t idx = ((size_t)i * C + o) * M + m;
-        outr[idx] = rr[j] + ii[j];
-        outi[idx] = ir[j] - ri[j];
+        part[ks][tile][0][lane * 4 + j] = rr[j] + ii[j];
+        part[ks][tile][1][lane * 4 + j] = ir[j] - ri[j];
+    }
+    __syncthreads();
+    if (ks == 0) {
+        float* outr = dst.dwr[l];
+        float* outi = dst.dwi[l];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float vr = part[0][tile][0][lane * 4 + j], vi = part[0][tile][1][lane * 4 + j];
+#pragma unroll
+            for (int k = 1; k < WG_KS; ++k) {
+                vr += part[k][tile][0][lane * 4 + j];
+                vi += part[k][tile][1][lane * 4 + j];
+            }
+            const int i = 16 * rt + 4 * q + j, o = 16 * ct + r;
+            const size_t idx = ((size_t)i * C + o) * M + m;
+            outr[idx] = vr;
+            outi[idx] = vi;
+        }
     }
 }
 
@@ -878,7 +886,7 @@ int fno_spec_wgrad(void* stream, const float* xspec, const float* gspec, int pai
         dst.dwr[l] = dwr[l];
         dst.dwi[l] = dwi[l];
     }
-    hipLaunchKernelGGL(fno_spec_wgrad_kernel, dim3(LAYERS * M), dim3(256), 0, (hipStream_t)stream, xspec, gspec, pairs, dst);
+    hipLaunchKernelGGL(fno_spec_wgrad_kernel, dim3(LAYERS * M), dim3(256 * WG_KS), 0, (hipStream_t)stream, xspec, gspec, pairs, dst);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(-2, "fno_spec_wgrad launch failed: %s", hipGetErrorString(e));
     return 0;

@@ -750,13 +750,17 @@ def unit_grad(device):
 def fused_delta_loss(surrogate, d_all, states, delta, mean, stdv):
     """d_all: time-major predicted deltas [T,B,1,N] (autograd output of the fused TBPTT forward); states [B,T,1,N].
     Returns (loss, hsteploss [T-1], stats [4] = mean/std of predicted then true deltas, true deltas [B,T-1,1,N])."""
-    owner = surrogate._fused_packs
+    owner = getattr(surrogate, "_fused_packs", None)
+    if owner is not None:
+        cache = owner.loss_scratch
+    else:                       # a surrogate without packs (the FNO path): the scratch hangs on the surrogate itself
+        cache = surrogate.__dict__.setdefault("_loss_scratch", {})
     t = d_all.shape[0]
-    scratch = owner.loss_scratch.get(t)
+    scratch = cache.get((t, d_all.device))
     if scratch is None:
         scratch = (torch.empty(40 * t, device=d_all.device, dtype=torch.float64),
                    torch.zeros(1, device=d_all.device, dtype=torch.int32))
-        owner.loss_scratch[t] = scratch
+        cache[(t, d_all.device)] = scratch
     return _DeltaLossFn.apply(d_all, states, float(delta), float(mean), float(stdv), scratch)
 
 

@@ -88,6 +88,16 @@ class PDETrainingModule(pl.LightningModule):
             out = ModelRollout(outputs=outputs, deltas=deltas, hidden=tuple(h.detach() for h in hidden))
             out.time_major_deltas = d_all
             return [out]
+        if states.is_cuda and ops.fused_enabled() and type(self.surrogate).__name__ == "FNOAutoRegSurrogate":
+            # the FNO surrogate's whole TBPTT pass as one autograd node on the whole-network kernels (csrc/fno.hip); None:
+            # a geometry they are not built for -> the generic chunk loop below (per-operator path)
+            from pdecontrol.surrogates import fno_hip
+            fused = fno_hip.tbptt(self.surrogate, states, actions, self.tau, self.tbtt, self._grid)
+            if fused is not None:
+                outputs, deltas, d_all = fused
+                out = ModelRollout(outputs=outputs, deltas=deltas, hidden=())
+                out.time_major_deltas = d_all
+                return [out]
         rollouts = []
         seed_states, hidden = None, None
         autoreg = isinstance(self.surrogate, AutoRegPDESurrogate)

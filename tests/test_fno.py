@@ -197,13 +197,13 @@ def test_whole_network_kernels_training_step_vs_cpu(n, scaled, B, T):
     ref = cpu.training_step((st, ac), 0)
     ref["loss"].backward()
     calls = []
-    orig = fno_hip._FNORolloutFn.apply
-    fno_hip._FNORolloutFn.apply = lambda *a: (calls.append(1), orig(*a))[1]
+    orig = fno_hip._FNOTBPTTFn.apply
+    fno_hip._FNOTBPTTFn.apply = lambda *a: (calls.append(1), orig(*a))[1]
     try:
         out = gpu.training_step((st.to(dev), ac.to(dev)), 0)
     finally:
-        fno_hip._FNORolloutFn.apply = orig
-    assert len(calls) == (2 if T > 10 else 1), "the rollout must run on the whole-network kernels, one node per chunk"
+        fno_hip._FNOTBPTTFn.apply = orig
+    assert len(calls) == 1, "the TBPTT pass must run on the whole-network kernels, as one autograd node"
     out["loss"].backward()
     torch.cuda.synchronize(dev)
     rel = abs(float(out["loss"].detach()) - float(ref["loss"].detach())) / abs(float(ref["loss"].detach()))
