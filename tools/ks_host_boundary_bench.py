@@ -1,6 +1,10 @@
 #!/usr/bin/env python3
 """PCIe-inclusive rate of the host-buffer entry points (never bench.py's `value`): ks_step_actions with
-numpy in / numpy out, one synchronisation per call."""
+numpy in / numpy out, one synchronisation per call.
+
+``sharded``: the vector-env API instead -- ``KSBatchedVecEnv.step`` on one handle against ``KSShardedVecEnv.step`` with the
+same envs on TWO (and four) handles of the SAME GPU: what the split entry (ks_step_begin on every shard, ks_step_end on
+one host thread per shard) costs or gains on the host side.  One GPU: not a scaling number."""
 import json
 import os
 import sys
@@ -17,6 +21,25 @@ if os.environ.get("KSPDE_LIB"):      # A/B of library builds
 from bench import forcing_matrix  # noqa: E402
 
 out = {}
+if "sharded" in sys.argv[1:]:
+    from pdegym.kuramoto import make_vec
+    for name, (E, N, L) in {"c2": (1024, 64, 22.0), "c3": (4096, 256, 88.0)}.items():
+        acts = np.random.RandomState(0).uniform(-1, 1, (30, E, 1, 4)).astype(np.float32)
+        res = {}
+        for label, kw in (("one_handle", dict(device=0)), ("two_handles_one_gpu", dict(devices=[0, 0])),
+                          ("four_handles_one_gpu", dict(devices=[0, 0, 0, 0]))):
+            env = make_vec(E, config=dict(L=L, N=N), burn_in=False, **kw)
+            env.reset(seed=0)
+            for i in range(5):
+                env.step(acts[i])
+            t0 = time.perf_counter()
+            for i in range(5, 30):
+                env.step(acts[i])
+            res[label] = {"ms_per_env_step": (time.perf_counter() - t0) / 25 * 1e3}
+            env.close()
+        out[name] = res
+    print(json.dumps(out))
+    sys.exit(0)
 for name, (E, N, L) in {"c2": (1024, 64, 22.0), "c3": (4096, 256, 88.0)}.items():
     s = kspde.KSStepper(E, N, L)
     s.set_forcing(forcing_matrix(L, N))
