@@ -15,7 +15,8 @@ is kept:
     just those envs; in ``reset_mode`` arithmetic -- "fast" by default, "exact" = the reference's
     realisation bit for bit, see kuramoto.py).
   * seeding: ``reset(seed=s)`` seeds env i with ``s + i`` (gym's vector convention); the IC of env
-    i is then exactly what the reference's ``reset(seed=s+i)`` draws.
+    i is then exactly what the reference's ``reset(seed=s+i)`` draws (``mt_batch.BatchedMT19937``: the
+    per-env MT19937 streams of all envs as array operations, bit-identical to one ``RandomState`` per env).
 
 Multi-GPU: envs are independent, so a job shards them by rank with ``shard_envs`` and every rank
 builds its own KSBatchedVecEnv on its own GPU; no collective is involved.  A SINGLE controller process (what
@@ -27,6 +28,7 @@ import numpy as np
 
 from pdegym._gym import gym
 from pdegym.kuramoto.kuramoto import KuramotoSivashinskyEnv, default_reset_mode
+from pdegym.kuramoto.mt_batch import BatchedMT19937
 
 DEFAULT_RESET_MODE = default_reset_mode
 
@@ -62,7 +64,7 @@ class KSBatchedVecEnv(gym.vector.VectorEnv):
             _stepper_cls = kspde.KSStepper
         self._build_steppers(_stepper_cls, variant)
         self.timestep = np.zeros(num_envs, dtype=np.int64)
-        self._rngs = [np.random.RandomState() for _ in range(num_envs)]
+        self._rng = BatchedMT19937(num_envs)      # one MT19937 stream per env (unseeded until reset(seed=...))
         self._actions = None
 
     def _build_steppers(self, stepper_cls, variant):
@@ -95,7 +97,7 @@ class KSBatchedVecEnv(gym.vector.VectorEnv):
     def _fresh_rows(self, ids: Sequence[int]):
         """New ICs for ``ids`` (kuramoto.py:106) and their burn-in (:108-109) on the GPU."""
         ids = np.asarray(ids, dtype=np.int32)
-        u0 = np.stack([self._rngs[i].uniform(-0.4, 0.4, size=self.N) for i in ids])
+        u0 = self._rng.uniform_rows(ids, -0.4, 0.4, self.N)
         self.stepper.set_state_rows(ids, u0)
         self._set_mode(self.reset_mode)
         obs, _, status = self.stepper.step_rows(ids, self.burn_in_substeps)
@@ -113,7 +115,7 @@ class KSBatchedVecEnv(gym.vector.VectorEnv):
         else:
             seeds = list(seed)
             assert len(seeds) == self.num_envs
-        self._rngs = [np.random.RandomState(s) for s in seeds]
+        self._rng.seed_rows(np.arange(self.num_envs), seeds)
         obs = self._fresh_rows(np.arange(self.num_envs))
         obs = obs.reshape(self.num_envs, 1, self.N)
         if return_info:

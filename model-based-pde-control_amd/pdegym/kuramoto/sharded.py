@@ -82,7 +82,7 @@ class KSShardedVecEnv(KSBatchedVecEnv):
     def _fresh_rows(self, ids):
         ids = np.asarray(ids, dtype=np.int64)
         n = len(ids)
-        u0 = np.stack([self._rngs[i].uniform(-0.4, 0.4, size=self.N) for i in ids]) if n else np.empty((0, self.N))
+        u0 = self._rng.uniform_rows(ids, -0.4, 0.4, self.N)
         obs = np.empty((n, self.N), dtype=np.float32)
         ssq = np.empty(n, dtype=np.float64)
         status = np.empty(n, dtype=np.int32)
