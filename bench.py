@@ -322,12 +322,16 @@ def episode_leg(run, reset_mode, ring=8):
     """What a real run of the reference's loop sees per episode (pdegym/kuramoto/kuramoto.py:100-116: the reset burn-in is
     800 step-equivalents, two thirds of all sub-steps): max_episode_steps = 400 steps of every env in the step arithmetic
     (fast), then the autoreset all envs take together -- fresh initial conditions uploaded + ONE launch of the 200 000
-    sub-step burn-in in ``reset_mode``.  Device resident like ``value`` (drawing the ICs with NumPy on the host is
-    outside the timed region and reported beside it)."""
+    sub-step burn-in in ``reset_mode``.  Device resident like ``value`` (seeding and drawing the ICs on the host --
+    pdegym/kuramoto/mt_batch.py, bit-identical to one RandomState per env -- is outside the timed region and reported
+    beside it)."""
     st, E, N, dev = run.stepper, run.E, run.N, run.dev
     steps, burn = 400, 200000
+    from pdegym.kuramoto.mt_batch import BatchedMT19937
     t0 = time.perf_counter()
-    u0 = np.stack([np.random.RandomState(4321 + e).uniform(-0.4, 0.4, N) for e in range(E)])
+    mt = BatchedMT19937(E)                # the vector envs' IC generator: env e <- RandomState(seed + e), as array operations
+    mt.seed_rows(np.arange(E), [4321 + e for e in range(E)])
+    u0 = mt.uniform_rows(np.arange(E), -0.4, 0.4, N)
     ic_ms = (time.perf_counter() - t0) * 1e3
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(dev)

@@ -39,6 +39,10 @@ def resolve_devices(spec):
 
 
 class KSShardedVecEnv(KSBatchedVecEnv):
+    #: observation bytes per shard from which the shards are collected on one host thread each (the host copy out of the
+    #: pinned mirror is what the threads parallelise)
+    THREADS_FROM_BYTES = 512 * 1024
+
     def __init__(self, num_envs: int, config: Optional[dict] = None, devices: Sequence[int] = (0,), **kwargs):
         self.devices = resolve_devices(devices)
         if num_envs < len(self.devices):
@@ -66,8 +70,19 @@ class KSShardedVecEnv(KSBatchedVecEnv):
 
     def _collect(self, jobs):
         """jobs: [(stepper, (obs, ssq, status) slices)] already begun; wait for all of them on the shard threads."""
-        if len(jobs) == 1:
-            jobs[0][0].step_end(jobs[0][1])
+        small = jobs and jobs[0][1][0] is not None and jobs[0][1][0].nbytes <= self.THREADS_FROM_BYTES
+        if len(jobs) == 1 or small:
+            # small blocks: waiting for the shards one after the other costs less than handing them to threads (1024 x 64
+            # on four handles: 1.9 ms per step through the pool, 0.3 ms in sequence); the devices run concurrently either
+            # way -- every launch was enqueued before the first wait
+            err = None
+            for st, out in jobs:
+                try:
+                    st.step_end(out)
+                except Exception as exc:       # noqa: BLE001
+                    err = err or exc
+            if err is not None:
+                raise err
             return
         futs = [self._pool.submit(st.step_end, out) for st, out in jobs]
         err = None
