@@ -15,31 +15,29 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "model-based-pde-control_amd"))
+out = {}
+if "sharded" in sys.argv[1:]:
+    # one fresh process per configuration (a real run builds ONE vector env; a process that has built and closed other
+    # handle sets before measures the runtime's stream / queue history: four handles at C2 read 2-3 ms that way, 0.44 ms fresh).
+    # This parent never touches the GPU.
+    import re
+    import subprocess
+    for name, (E, N, L) in {"c2": (1024, 64, 22.0), "c3": (4096, 256, 88.0)}.items():
+        res = {}
+        for label, handles in (("one_handle", 1), ("two_handles_one_gpu", 2), ("four_handles_one_gpu", 4)):
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sharded_trace_run.py"), str(E), str(N), str(L), str(handles)],
+                               capture_output=True, text=True, timeout=600)
+            m = re.search(r"ms per step ([0-9.]+)\s+\(step_async ([0-9.]+), step_wait ([0-9.]+)\)", r.stdout)
+            res[label] = ({"ms_per_env_step": float(m.group(1)), "step_async_ms": float(m.group(2)), "step_wait_ms": float(m.group(3))}
+                          if m else {"error": (r.stderr or r.stdout)[-300:]})
+        out[name] = res
+    print(json.dumps(out))
+    sys.exit(0)
 import kspde  # noqa: E402
 if os.environ.get("KSPDE_LIB"):      # A/B of library builds
     kspde.LIB_PATH = os.path.abspath(os.environ["KSPDE_LIB"])
 from bench import forcing_matrix  # noqa: E402
 
-out = {}
-if "sharded" in sys.argv[1:]:
-    from pdegym.kuramoto import make_vec
-    for name, (E, N, L) in {"c2": (1024, 64, 22.0), "c3": (4096, 256, 88.0)}.items():
-        acts = np.random.RandomState(0).uniform(-1, 1, (30, E, 1, 4)).astype(np.float32)
-        res = {}
-        for label, kw in (("one_handle", dict(device=0)), ("two_handles_one_gpu", dict(devices=[0, 0])),
-                          ("four_handles_one_gpu", dict(devices=[0, 0, 0, 0]))):
-            env = make_vec(E, config=dict(L=L, N=N), burn_in=False, **kw)
-            env.reset(seed=0)
-            for i in range(5):
-                env.step(acts[i])
-            t0 = time.perf_counter()
-            for i in range(5, 30):
-                env.step(acts[i])
-            res[label] = {"ms_per_env_step": (time.perf_counter() - t0) / 25 * 1e3}
-            env.close()
-        out[name] = res
-    print(json.dumps(out))
-    sys.exit(0)
 for name, (E, N, L) in {"c2": (1024, 64, 22.0), "c3": (4096, 256, 88.0)}.items():
     s = kspde.KSStepper(E, N, L)
     s.set_forcing(forcing_matrix(L, N))
