@@ -678,6 +678,383 @@ __device__ void rb_backward(const RBBuf& b, const float* const* w, float* const*
 #undef RB_STAMP
 }
 
+// ---------------------------------------------------------------------------------------------
+// Narrow residual block: every channel count <= 4 (the action encoder, 1 -> 2 -> 4 -> 4) -- on the VALU, ONE WAVE PER SAMPLE.
+// The MFMA gather-GEMM path spends its instructions on tile bookkeeping, index functors and masks whatever the channel
+// counts: ~11 k wave-instructions per sample and block backward for ~10 k useful multiply-adds, and these kernels are
+// instruction-issue bound.  Here a lane owns the positions p = lane + 64 e of every channel, keeps
+// its values in registers, reads convolution neighbours from a wave-private LDS copy, reduces LayerNorm statistics and
+// weight gradients with DPP row rotations; the four waves of a workgroup handle four samples independently (no
+// workgroup barrier inside a pass), sharing the staged weights.  Records in `saved`, outputs and partial-gradient rows
+// are laid out exactly as the MFMA path leaves them.
+// ---------------------------------------------------------------------------------------------
+constexpr int NR_C = 4;   // channels
+// positions per lane: at most 2 (block outputs are <= 128 wide, inputs that need a gradient too: N <= 256)
+
+__host__ __device__ inline bool enc_narrow(const sur_encoder_params& p) {
+    // block 0: 1 -> <= 2 channels onto <= 128 positions (tile 2 x 2, no input gradient); block 1: <= 2 -> <= 4 channels, <= 128 ->
+    // <= 64 positions; block 2: <= 4 -> <= 4 channels on <= 64 positions
+    if (p.c[0] != 1 || p.c[1] > 2 || p.c[2] > NR_C || p.c[3] > NR_C) return false;
+    for (int b = 0; b < 3; ++b)
+        if (p.stride[b] != 1 && p.stride[b] != 2) return false;
+    const int h1 = p.n / p.stride[0], h2 = h1 / p.stride[1], h3 = h2 / p.stride[2];
+    return h1 <= 128 && h2 <= 64 && h3 <= 64 && h3 == h2 && (h1 & 7) == 0 && (h2 & 7) == 0;
+}
+
+// LDS traffic between the lanes of ONE wave: make the wave's own writes visible to its later reads
+#define NR_WAVE_SYNC()                                           \
+    do {                                                          \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    \
+        __builtin_amdgcn_wave_barrier();                          \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    \
+    } while (0)
+
+// totals of a and b over the whole wave, returned wave-uniform (SGPRs): four rotations inside the rows of 16 lanes, two DPP row
+// broadcasts across the rows, one v_readlane -- no trip through the LDS crossbar (group_sum2's 16- and 32-lane steps are
+// ds_bpermute round trips; a wave that owns a whole sample has nothing to hide them behind)
+template <int CTRL, int ROWS>
+__device__ __forceinline__ float nr_bcast_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROWS, 0xf, false));
+}
+__device__ __forceinline__ void nr_wave_sum2(float& a, float& b) {
+    a += dpp_rot<0x128>(a);  // row_ror:8
+    b += dpp_rot<0x128>(b);
+    a += dpp_rot<0x124>(a);  // row_ror:4
+    b += dpp_rot<0x124>(b);
+    a += dpp_rot<0x122>(a);  // row_ror:2
+    b += dpp_rot<0x122>(b);
+    a += dpp_rot<0x121>(a);  // row_ror:1
+    b += dpp_rot<0x121>(b);
+    a = nr_bcast_add<0x142, 0xa>(a);   // row_bcast:15 into rows 1 and 3
+    b = nr_bcast_add<0x142, 0xa>(b);
+    a = nr_bcast_add<0x143, 0xc>(a);   // row_bcast:31 into rows 2 and 3: lane 63 holds the total
+    b = nr_bcast_add<0x143, 0xc>(b);
+    a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), 63));
+    b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b), 63));
+}
+
+// A lane's values of a [C][H] activation: channels c < TC, positions lane + 64 e, e < TE.  TC / TE are compile-time bounds
+// (the kernels instantiate the three shapes of the 1 -> 2 -> 4 -> 4 encoder and a generic 4 x 2 fallback): a tile is 4 to 8
+// registers, so the residual block's working set stays far below the 128-VGPR budget the MFMA path of the same kernel has.
+template <int TC, int TE>
+struct NrTile {
+    float v[TC][TE];
+};
+
+// a value every lane of the wave holds alike (a staged weight read from LDS): kept in an SGPR instead of a VGPR per weight
+__device__ __forceinline__ float nr_uniform(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
+
+template <int TC, int TE>
+__device__ __forceinline__ void nr_load(const float* buf, int C, int H, int lane, NrTile<TC, TE>& t) {
+#pragma unroll
+    for (int c = 0; c < TC; ++c)
+#pragma unroll
+        for (int e = 0; e < TE; ++e) {
+            const int p = lane + 64 * e;
+            t.v[c][e] = (c < C && p < H) ? buf[c * H + p] : 0.0f;
+        }
+}
+template <int TC, int TE>
+__device__ __forceinline__ void nr_store(float* buf, int C, int H, int lane, const NrTile<TC, TE>& t) {
+#pragma unroll
+    for (int c = 0; c < TC; ++c)
+#pragma unroll
+        for (int e = 0; e < TE; ++e) {
+            const int p = lane + 64 * e;
+            if (c < C && p < H) buf[c * H + p] = t.v[c][e];
+        }
+}
+
+// out[o][p] = sum_{ci,k} W[o][ci][k] * in[ci][(p*stride + k - pad) mod hin] for the lane's own output positions (IC >= cin)
+template <int K, int IC, int TC, int TE>
+__device__ __forceinline__ void nr_conv(const float* in, int cin, int hin, const float* W, int cout, int stride, int pad, int hout,
+                                        int lane, NrTile<TC, TE>& out) {
+#pragma unroll
+    for (int e = 0; e < TE; ++e) {
+        const int p = lane + 64 * e;
+        int idx[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) idx[k] = wrapi((p < hout ? p : 0) * stride + k - pad, hin);
+        float x[IC][K];
+#pragma unroll
+        for (int ci = 0; ci < IC; ++ci)
+#pragma unroll
+            for (int k = 0; k < K; ++k) x[ci][k] = ci < cin ? in[ci * hin + idx[k]] : 0.0f;
+#pragma unroll
+        for (int o = 0; o < TC; ++o) {
+            float acc = 0.0f;
+            if (o < cout) {
+#pragma unroll
+                for (int ci = 0; ci < IC; ++ci)
+                    if (ci < cin) {
+#pragma unroll
+                        for (int k = 0; k < K; ++k) acc = fmaf(nr_uniform(W[(o * cin + ci) * K + k]), x[ci][k], acc);
+                    }
+            }
+            out.v[o][e] = p < hout ? acc : 0.0f;
+        }
+    }
+}
+
+// y = LayerNorm_H(act(x)) * gamma + beta, rows = channels, statistics over the 64 lanes x TE positions
+template <int TC, int TE>
+__device__ __forceinline__ void nr_ln_fwd(const NrTile<TC, TE>& x, int C, int H, const float* gamma, const float* beta, bool silu,
+                                          int lane, NrTile<TC, TE>& y) {
+    const float inv_h = 1.0f / H;
+#pragma unroll
+    for (int c = 0; c < TC; ++c) {
+        float a[TE], s = 0.0f, ss = 0.0f;
+#pragma unroll
+        for (int e = 0; e < TE; ++e) {
+            const bool live = c < C && lane + 64 * e < H;
+            const float v = x.v[c][e];
+            a[e] = live ? (silu ? v * sigmoid_(v) : v) : 0.0f;
+            s += a[e];
+            ss = fmaf(a[e], a[e], ss);
+        }
+        nr_wave_sum2(s, ss);
+        const float mean = s * inv_h;
+        const float rstd = rsqrtf(fmaxf(fmaf(-mean, mean, ss * inv_h), 0.0f) + LN_EPS);
+#pragma unroll
+        for (int e = 0; e < TE; ++e) {
+            const int p = lane + 64 * e;
+            y.v[c][e] = (c < C && p < H) ? fmaf((a[e] - mean) * rstd, gamma[p], beta[p]) : 0.0f;
+        }
+    }
+}
+
+// backward of nr_ln_fwd: dpre from dout; the lane adds its own positions' gamma / beta gradients to the wave's accumulators
+template <int TC, int TE>
+__device__ __forceinline__ void nr_ln_bwd(const NrTile<TC, TE>& dout, const NrTile<TC, TE>& pre, int C, int H, const float* gamma,
+                                          bool silu, int lane, NrTile<TC, TE>& dpre, float* ggamma, float* gbeta) {
+    const float inv_h = 1.0f / H;
+    float gg[TE], gb[TE];
+#pragma unroll
+    for (int e = 0; e < TE; ++e) gg[e] = gb[e] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < TC; ++c) {
+        float y[TE], dxh[TE], s = 0.0f, ss = 0.0f;
+#pragma unroll
+        for (int e = 0; e < TE; ++e) {
+            const int p = lane + 64 * e;
+            const bool live = c < C && p < H;
+            const float v = pre.v[c][e];
+            y[e] = live ? (silu ? v * sigmoid_(v) : v) : 0.0f;
+            dxh[e] = live ? dout.v[c][e] * gamma[p] : 0.0f;
+            s += y[e];
+            ss = fmaf(y[e], y[e], ss);
+        }
+        nr_wave_sum2(s, ss);
+        const float mean = s * inv_h;
+        const float rstd = rsqrtf(fmaxf(fmaf(-mean, mean, ss * inv_h), 0.0f) + LN_EPS);
+        float m1 = 0.0f, m2 = 0.0f;
+#pragma unroll
+        for (int e = 0; e < TE; ++e) {
+            const bool live = c < C && lane + 64 * e < H;
+            y[e] = live ? (y[e] - mean) * rstd : 0.0f;     // xhat
+            m1 += dxh[e];
+            m2 = fmaf(dxh[e], y[e], m2);
+        }
+        nr_wave_sum2(m1, m2);
+        m1 *= inv_h;
+        m2 *= inv_h;
+#pragma unroll
+        for (int e = 0; e < TE; ++e) {
+            const bool live = c < C && lane + 64 * e < H;
+            float dy = rstd * (dxh[e] - m1 - y[e] * m2);
+            if (silu) {
+                const float v = pre.v[c][e], sg = sigmoid_(v);
+                dy *= sg * (1.0f + v * (1.0f - sg));
+            }
+            dpre.v[c][e] = live ? dy : 0.0f;
+            if (live) {
+                gg[e] = fmaf(dout.v[c][e], y[e], gg[e]);
+                gb[e] += dout.v[c][e];
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < TE; ++e) {
+        const int p = lane + 64 * e;
+        if (p < H) {
+            ggamma[p] += gg[e];
+            gbeta[p] += gb[e];
+        }
+    }
+}
+
+// gW[o][ci][k] += sum_p dout[o][p] * in[ci][(p*stride + k - pad) mod hin]   (dout [cout][hout] and in [cin][hin]: this wave's LDS)
+// One 16 x 16 MFMA tile: rows = output channels (cout <= 4 of 16), columns = (ci, k) (cin * K <= 12 of 16), reduction over the
+// positions four at a time.  Mostly empty, and still ~50 instructions where 64-lane reductions of every weight's partial
+// products took ~700: the tile does the cross-lane summation.  hout is a multiple of 8 (enc_narrow).
+template <int K>
+__device__ __forceinline__ void nr_wgrad(const float* dout, const float* in, int cin, int hin, int cout, int stride, int pad, int hout,
+                                         int lane, float* gW) {
+    const int r = lane & 15, q = lane >> 4, ncol = cin * K;
+    const bool a_ok = r < cout, b_ok = r < ncol;
+    const int ci = b_ok ? r / K : 0, k = b_ok ? r - ci * K : 0;
+    const float* ap = dout + (a_ok ? r : 0) * hout;
+    const float* bp = in + ci * hin;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    for (int p0 = 0; p0 < hout; p0 += 8) {
+        const int pa = p0 + q, pb = p0 + 4 + q;
+        const float a0 = ap[pa], b0 = bp[wrapi(pa * stride + k - pad, hin)];
+        const float a1 = ap[pb], b1 = bp[wrapi(pb * stride + k - pad, hin)];
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_ok ? a0 : 0.f, b_ok ? b0 : 0.f, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_ok ? a1 : 0.f, b_ok ? b1 : 0.f, acc1, 0, 0, 0);
+    }
+    if (q == 0 && b_ok) {        // rows 0..3 of the tile live in lanes 0..15
+#pragma unroll
+        for (int o = 0; o < NR_C; ++o)
+            if (o < cout) gW[o * ncol + r] += acc0[o] + acc1[o];
+    }
+}
+
+// din[ci][j] (+)= sum_{o,k : (p*stride + k - pad) mod hin == j} W[o][ci][k] * dout[o][p]   (dout: LDS, din: own positions; OC >= cout)
+template <int K, int OC, int IC, int IE>
+__device__ __forceinline__ void nr_dgrad(const float* dout, int cout, int hin, const float* W, int cin, int stride, int pad, int hout,
+                                         int lane, NrTile<IC, IE>& din, bool accumulate) {
+#pragma unroll
+    for (int e = 0; e < IE; ++e) {
+        const int j = lane + 64 * e;
+        const bool live = j < hin;
+        float acc[IC];
+#pragma unroll
+        for (int ci = 0; ci < IC; ++ci) acc[ci] = accumulate ? din.v[ci][e] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int t = wrapi((live ? j : 0) - k + pad, hin);
+            if ((t & (stride - 1)) == 0) {
+                const int pp = t >> (stride - 1);
+#pragma unroll
+                for (int o = 0; o < OC; ++o) {
+                    if (o >= cout) break;
+                    const float d = dout[o * hout + pp];
+#pragma unroll
+                    for (int ci = 0; ci < IC; ++ci)
+                        if (ci < cin) acc[ci] = fmaf(nr_uniform(W[(o * cin + ci) * K + k]), d, acc[ci]);
+                }
+            }
+        }
+#pragma unroll
+        for (int ci = 0; ci < IC; ++ci) din.v[ci][e] = (ci < cin && live) ? acc[ci] : 0.0f;
+    }
+}
+
+// floats of one wave's LDS region
+__host__ __device__ inline int nr_fwd_wave_floats(int cin, int hin, int cout, int hout) { return cin * hin + 7 * cout * hout; }
+__host__ __device__ inline int nr_bwd_wave_floats(int cin, int hin, int cout, int hout, int psize_blk) {
+    return cin * hin + 6 * cout * hout + ((psize_blk + 3) & ~3);   // in | a1pre a1 a2pre | s | dout | gbuf | gradient accumulators
+}
+
+// forward of one block for one sample: `wl` = this wave's LDS region; record layout skip | a1pre | a1 | a2pre | a2 | s | out
+template <int IC, int TC, int TE>
+__device__ __forceinline__ void nr_block_forward_t(int cin, int hin, int cout, int hout, int stride, const float* const* w, float* wl,
+                                                   const float* __restrict__ src, float* __restrict__ rec_out, float* __restrict__ z,
+                                                   int lane) {
+    typedef NrTile<TC, TE> T;
+    const int a = cout * hout, nin = cin * hin;
+    float* in = wl;
+    float* skip = in + nin;
+    float *a1pre = skip + a, *a1 = skip + 2 * a, *a2pre = skip + 3 * a, *a2 = skip + 4 * a, *sb = skip + 5 * a, *out = skip + 6 * a;
+    for (int i = lane; i < nin; i += 64) in[i] = src[i];
+    NR_WAVE_SYNC();
+    T t_skip, t_pre, t_act;
+    nr_conv<1, IC>(in, cin, hin, w[SUR_RB_SKIP], cout, stride, 0, hout, lane, t_skip);
+    nr_conv<3, IC>(in, cin, hin, w[SUR_RB_CONV1], cout, stride, 1, hout, lane, t_pre);
+    nr_store(skip, cout, hout, lane, t_skip);
+    nr_store(a1pre, cout, hout, lane, t_pre);
+    nr_ln_fwd(t_pre, cout, hout, w[SUR_RB_LN1_W], w[SUR_RB_LN1_B], true, lane, t_act);
+    nr_store(a1, cout, hout, lane, t_act);
+    NR_WAVE_SYNC();
+    nr_conv<3, TC>(a1, cout, hout, w[SUR_RB_CONV2], cout, 1, 1, hout, lane, t_pre);
+    nr_store(a2pre, cout, hout, lane, t_pre);
+    nr_ln_fwd(t_pre, cout, hout, w[SUR_RB_LN2_W], w[SUR_RB_LN2_B], true, lane, t_act);
+    nr_store(a2, cout, hout, lane, t_act);
+#pragma unroll
+    for (int c = 0; c < TC; ++c)
+#pragma unroll
+        for (int e = 0; e < TE; ++e) t_act.v[c][e] += t_skip.v[c][e];
+    nr_store(sb, cout, hout, lane, t_act);
+    nr_ln_fwd(t_act, cout, hout, w[SUR_RB_LN3_W], w[SUR_RB_LN3_B], false, lane, t_pre);
+    nr_store(out, cout, hout, lane, t_pre);
+    NR_WAVE_SYNC();
+    for (int i = lane; i < (7 * a) >> 2; i += 64) reinterpret_cast<float4*>(rec_out)[i] = reinterpret_cast<const float4*>(skip)[i];
+    if (z)
+        for (int i = lane; i < a; i += 64) z[i] = out[i];
+    NR_WAVE_SYNC();      // the region is reused by this wave's next sample
+}
+
+__device__ __forceinline__ void nr_block_forward(int cin, int hin, int cout, int hout, int stride, const float* const* w, float* wl,
+                                                 const float* __restrict__ src, float* __restrict__ rec_out, float* __restrict__ z, int lane) {
+    if (cin <= 1 && cout <= 2) nr_block_forward_t<1, 2, 2>(cin, hin, cout, hout, stride, w, wl, src, rec_out, z, lane);
+    else nr_block_forward_t<4, 4, 1>(cin, hin, cout, hout, stride, w, wl, src, rec_out, z, lane);      // hout <= 64 (enc_narrow)
+}
+
+// backward of one block for one sample; g[] = this wave's gradient accumulators (LDS)
+template <int TC, int TE, int IC, int IE>
+__device__ __forceinline__ void nr_block_backward_t(int cin, int hin, int cout, int hout, int stride, const float* const* w, float* const* g,
+                                                    float* wl, const float* __restrict__ in_src, const float* __restrict__ rec_blk,
+                                                    const float* __restrict__ dsrc, float* __restrict__ din_dst, bool need_din, int lane) {
+    typedef NrTile<TC, TE> T;
+    const int a = cout * hout, nin = cin * hin;
+    float* in = wl;
+    float* a1pre = in + nin;
+    float *a1 = a1pre + a, *a2pre = a1pre + 2 * a, *sb = a1pre + 3 * a, *dout = a1pre + 4 * a, *gbuf = a1pre + 5 * a;
+    for (int i = lane; i < nin; i += 64) in[i] = in_src[i];
+    for (int i = lane; i < 3 * a; i += 64) a1pre[i] = rec_blk[a + i];            // a1pre | a1 | a2pre
+    for (int i = lane; i < a; i += 64) {
+        sb[i] = rec_blk[5 * a + i];
+        dout[i] = dsrc[i];
+    }
+    NR_WAVE_SYNC();
+    T t_d, t_x, t_g;
+    NrTile<IC, IE> t_din;
+    nr_load(dout, cout, hout, lane, t_d);
+    nr_load(sb, cout, hout, lane, t_x);
+    nr_ln_bwd(t_d, t_x, cout, hout, w[SUR_RB_LN3_W], false, lane, t_g, g[SUR_RB_LN3_W], g[SUR_RB_LN3_B]);       // g1
+    nr_store(gbuf, cout, hout, lane, t_g);
+    NR_WAVE_SYNC();
+    nr_wgrad<1>(gbuf, in, cin, hin, cout, stride, 0, hout, lane, g[SUR_RB_SKIP]);
+    if (need_din) nr_dgrad<1, TC>(gbuf, cout, hin, w[SUR_RB_SKIP], cin, stride, 0, hout, lane, t_din, false);
+    nr_load(a2pre, cout, hout, lane, t_x);
+    nr_ln_bwd(t_g, t_x, cout, hout, w[SUR_RB_LN2_W], true, lane, t_d, g[SUR_RB_LN2_W], g[SUR_RB_LN2_B]);         // g2 (in t_d)
+    NR_WAVE_SYNC();       // every lane has read g1 from gbuf
+    nr_store(gbuf, cout, hout, lane, t_d);
+    NR_WAVE_SYNC();
+    nr_wgrad<3>(gbuf, a1, cout, hout, cout, 1, 1, hout, lane, g[SUR_RB_CONV2]);
+    nr_dgrad<3, TC>(gbuf, cout, hout, w[SUR_RB_CONV2], cout, 1, 1, hout, lane, t_g, false);                        // g3 (in t_g)
+    nr_load(a1pre, cout, hout, lane, t_x);
+    nr_ln_bwd(t_g, t_x, cout, hout, w[SUR_RB_LN1_W], true, lane, t_d, g[SUR_RB_LN1_W], g[SUR_RB_LN1_B]);         // g1' (in t_d)
+    NR_WAVE_SYNC();
+    nr_store(gbuf, cout, hout, lane, t_d);
+    NR_WAVE_SYNC();
+    nr_wgrad<3>(gbuf, in, cin, hin, cout, stride, 1, hout, lane, g[SUR_RB_CONV1]);
+    if (need_din) {
+        nr_dgrad<3, TC>(gbuf, cout, hin, w[SUR_RB_CONV1], cin, stride, 1, hout, lane, t_din, true);
+#pragma unroll
+        for (int c = 0; c < IC; ++c)
+#pragma unroll
+            for (int e = 0; e < IE; ++e) {
+                const int j = lane + 64 * e;
+                if (c < cin && j < hin) din_dst[c * hin + j] = t_din.v[c][e];
+            }
+    }
+    NR_WAVE_SYNC();
+}
+
+__device__ __forceinline__ void nr_block_backward(int cin, int hin, int cout, int hout, int stride, const float* const* w, float* const* g,
+                                                  float* wl, const float* __restrict__ in_src, const float* __restrict__ rec_blk,
+                                                  const float* __restrict__ dsrc, float* __restrict__ din_dst, bool need_din, int lane) {
+    // the three shapes of the 1 -> 2 -> 4 -> 4 encoder (N <= 256); enc_narrow() admits nothing else
+    if (!need_din && cin <= 1 && cout <= 2)
+        nr_block_backward_t<2, 2, 1, 1>(cin, hin, cout, hout, stride, w, g, wl, in_src, rec_blk, dsrc, din_dst, false, lane);
+    else if (hout <= 64 && cin <= 2 && hin <= 128)
+        nr_block_backward_t<4, 1, 2, 2>(cin, hin, cout, hout, stride, w, g, wl, in_src, rec_blk, dsrc, din_dst, need_din, lane);
+    else      // hout <= 64, hin <= 64 (enc_narrow)
+        nr_block_backward_t<4, 1, 4, 1>(cin, hin, cout, hout, stride, w, g, wl, in_src, rec_blk, dsrc, din_dst, need_din, lane);
+}
+
 struct EncLayout {
     RBBuf rb[3];
     float *g1, *g2, *g3, *xh, *dA, *dB, *end;
@@ -978,13 +1355,139 @@ __device__ __forceinline__ void enc_block_bwd_body(const EncBlockJob& j, int blk
     STAMP(sbase + 10);
 }
 
+
+// The narrow jobs of a launch set (one wave per sample, see "Narrow residual block") run in kernels of their own, ONE job per
+// launch, with a flat argument block whose arrays are only ever indexed by constants (inside the MFMA kernels the two paths
+// shared one register allocation and the job structs -- indexed by the block number -- went through scratch: 3 KB per lane).
+struct NarrowJob {
+    const float* w[SUR_RB_NPARAM];   // this block's weights (global)
+    int size[SUR_RB_NPARAM];
+    int cin, hin, cout, hout, stride;
+    int nsv, nws;                    // floats per sample of the saved record / of the inter-block gradient workspace
+    int saved_off, in_saved_off;     // this block's intermediates / its input inside a record (-1: the raw input x)
+    int ws_in_off, ws_out_off;       // where the block writes d loss / d input, reads d loss / d output (blocks 1, 0)
+    int blk, m, wg_count, psize_blk, need_din;
+    const float* x;
+    const float* dz;                 // backward, block 2: d loss / d z
+    float* z;                        // forward, block 2: the encoder output
+    float* saved;
+    float* ws;
+    float* rows;                     // backward: &partial[row_base][param_off]; workgroup wg adds to rows + wg * row_stride
+    int row_stride;
+};
+
+__device__ __forceinline__ void narrow_stage(const NarrowJob& j, float* dst, const float** w) {
+    int off = 0;
+#pragma unroll
+    for (int i = 0; i < SUR_RB_NPARAM; ++i) {
+        w[i] = dst + off;
+        for (int t = threadIdx.x; t < j.size[i]; t += blockDim.x) dst[off + t] = j.w[i][t];
+        off += j.size[i];
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void enc_narrow_fwd_run(const NarrowJob& j, int wg, float* lds) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwv = blockDim.x >> 6;
+    const int a = j.cout * j.hout, nin = j.cin * j.hin;
+    const int wf = nr_fwd_wave_floats(j.cin, j.hin, j.cout, j.hout);
+    const float* w[SUR_RB_NPARAM];
+    narrow_stage(j, lds + nwv * wf, w);
+    const int passes = (j.m + nwv - 1) / nwv;
+    for (int mp = wg; mp < passes; mp += j.wg_count) {
+        const int m = mp * nwv + wave;
+        if (m < j.m) {
+            float* rec = j.saved + (size_t)m * j.nsv;
+            const float* src = j.in_saved_off < 0 ? j.x + (size_t)m * nin : rec + j.in_saved_off;
+            nr_block_forward(j.cin, j.hin, j.cout, j.hout, j.stride, w, lds + wave * wf, src, rec + j.saved_off,
+                             j.z ? j.z + (size_t)m * a : nullptr, lane);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(TPB) enc_narrow_fwd_kernel(const NarrowJob j) {
+    extern __shared__ __align__(16) float lds[];
+    enc_narrow_fwd_run(j, blockIdx.x, lds);
+}
+
+__device__ __forceinline__ void enc_narrow_bwd_run(const NarrowJob& j, int wg, float* lds) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwv = blockDim.x >> 6;
+    const int a = j.cout * j.hout, nin = j.cin * j.hin;
+    const int wf = nr_bwd_wave_floats(j.cin, j.hin, j.cout, j.hout, j.psize_blk);
+    float* wl = lds + wave * wf;
+    float* gacc = wl + nin + 6 * a;
+    const float* w[SUR_RB_NPARAM];
+    float* g[SUR_RB_NPARAM];
+    {
+        int off = 0;
+#pragma unroll
+        for (int i = 0; i < SUR_RB_NPARAM; ++i) {
+            g[i] = gacc + off;
+            off += j.size[i];
+        }
+        for (int i = lane; i < j.psize_blk; i += 64) gacc[i] = 0.0f;
+    }
+    narrow_stage(j, lds + nwv * wf, w);
+    const int passes = (j.m + nwv - 1) / nwv;
+    for (int mp = wg; mp < passes; mp += j.wg_count) {
+        const int m = mp * nwv + wave;
+        if (m < j.m) {
+            const float* rec = j.saved + (size_t)m * j.nsv;
+            const float* in_src = j.in_saved_off < 0 ? j.x + (size_t)m * nin : rec + j.in_saved_off;
+            const float* dsrc = j.blk == 2 ? j.dz + (size_t)m * a : j.ws + (size_t)m * j.nws + j.ws_out_off;
+            float* din_dst = j.need_din ? j.ws + (size_t)m * j.nws + j.ws_in_off : nullptr;
+            nr_block_backward(j.cin, j.hin, j.cout, j.hout, j.stride, w, g, wl, in_src, rec + j.saved_off, dsrc, din_dst, j.need_din != 0,
+                              lane);
+        }
+    }
+    __syncthreads();
+    float* row = j.rows + (size_t)wg * j.row_stride;
+    for (int i = threadIdx.x; i < j.psize_blk; i += blockDim.x) {
+        float t = 0.0f;
+        for (int wv = 0; wv < nwv; ++wv) t += lds[wv * wf + nin + 6 * a + i];
+        row[i] += t;
+    }
+}
+
+__global__ void __launch_bounds__(TPB) enc_narrow_bwd_kernel(const NarrowJob j) {
+    extern __shared__ __align__(16) float lds[];
+    enc_narrow_bwd_run(j, blockIdx.x, lds);
+}
+
+static NarrowJob narrow_job(const sur_encoder_params& p, int blk, int m) {
+    NarrowJob j{};
+    const EncBlockGeom gm = enc_block_geom(p, blk);
+    for (int i = 0; i < SUR_RB_NPARAM; ++i) {
+        j.w[i] = p.w[SUR_RB_NPARAM * blk + i];
+        j.size[i] = p.size[SUR_RB_NPARAM * blk + i];
+    }
+    j.cin = gm.cin; j.hin = gm.hin; j.cout = gm.cout; j.hout = gm.hout; j.stride = gm.stride;
+    j.nsv = enc_saved_floats(p);
+    j.nws = enc_ws_floats(p);
+    j.saved_off = gm.saved_off;
+    j.in_saved_off = gm.in_saved_off;
+    const int h1 = p.n / p.stride[0];
+    j.ws_in_off = blk == 2 ? p.c[1] * h1 : 0;
+    j.ws_out_off = blk == 1 ? p.c[1] * h1 : 0;
+    j.blk = blk;
+    j.m = m;
+    j.psize_blk = gm.psize_blk;
+    j.need_din = blk > 0 ? 1 : 0;
+    return j;
+}
+
 #ifndef ENC_BLK_OCC
 #define ENC_BLK_OCC 4   // 128 VGPRs (a few spilled dwords): four workgroups per CU measured best
 #endif
 __global__ void __launch_bounds__(TPB, ENC_BLK_OCC)
-enc_block_bwd_multi_kernel(const EncBlockJob j0, const EncBlockJob j1, const EncBlockJob j2, int njobs, int blk) {
+enc_block_bwd_multi_kernel(const EncBlockJob j0, const EncBlockJob j1, const EncBlockJob j2, int njobs, int blk, const NarrowJob nj,
+                           int narrow_begin) {
     extern __shared__ __align__(16) float lds[];
     const int wg = blockIdx.x;
+    if (wg >= narrow_begin) {      // the workgroups behind the wide jobs' carry the narrow job (one wave per sample)
+        enc_narrow_bwd_run(nj, wg - narrow_begin, lds);
+        return;
+    }
     if (njobs > 2 && wg >= j2.wg_begin) enc_block_bwd_body(j2, blk, wg - j2.wg_begin, lds);
     else if (njobs > 1 && wg >= j1.wg_begin) enc_block_bwd_body(j1, blk, wg - j1.wg_begin, lds);
     else enc_block_bwd_body(j0, blk, wg, lds);
@@ -1028,10 +1531,15 @@ __device__ __forceinline__ void enc_block_fwd_body(const EncFwdJob& j, int blk, 
     }
 }
 
+
 __global__ void __launch_bounds__(TPB, ENC_BLK_OCC)
-enc_block_fwd_multi_kernel(const EncFwdJob j0, const EncFwdJob j1, int njobs, int blk) {
+enc_block_fwd_multi_kernel(const EncFwdJob j0, const EncFwdJob j1, int njobs, int blk, const NarrowJob nj, int narrow_begin) {
     extern __shared__ __align__(16) float lds[];
     const int wg = blockIdx.x;
+    if (wg >= narrow_begin) {
+        enc_narrow_fwd_run(nj, wg - narrow_begin, lds);
+        return;
+    }
     if (njobs > 1 && wg >= j1.wg_begin) enc_block_fwd_body(j1, blk, wg - j1.wg_begin, lds);
     else enc_block_fwd_body(j0, blk, wg, lds);
 }
@@ -2381,9 +2889,11 @@ int sur_encoder_forward_multi(void* stream, int njobs, const sur_encoder_params*
     if (njobs < 1 || njobs > 2 || !ps || !xs || !ms || !zs || !saveds || max_workgroups <= 0)
         return fail(-1, "sur_encoder_forward_multi: bad argument (1 or 2 jobs)");
     for (int blk = 0; blk < 3; ++blk) {
-        EncFwdJob jobs[2] = {};
-        size_t lds = 0;
-        int grid = 0;
+        // the jobs of this block, wide (MFMA kernels) and narrow (one wave per sample) ones in a launch each
+        EncFwdJob wide[2] = {};
+        NarrowJob narrow[2] = {};
+        size_t lds_w = 0;
+        int grid_w = 0, nw = 0, nn = 0;
         for (int j = 0; j < njobs; ++j) {
             const sur_encoder_params* p = ps[j];
             if (!p || !xs[j] || !zs[j] || !saveds[j] || ms[j] <= 0)
@@ -2391,17 +2901,44 @@ int sur_encoder_forward_multi(void* stream, int njobs, const sur_encoder_params*
             if (sur_encoder_saved_floats(p) == 0) return fail(-4, "sur_encoder_forward_multi: job %d: geometry not float4-granular", j);
             if (p->n > 64 * LN_MAX_EPL * p->stride[0]) return fail(-4, "sur_encoder_forward_multi: N = %d too wide for the fused LayerNorm", p->n);
             const EncBlockGeom gm = enc_block_geom(*p, blk);
-            const size_t need = sizeof(float) * (gm.cin * gm.hin + 7 * gm.cout * gm.hout + gm.psize_blk);
-            lds = need > lds ? need : lds;
-            const int wgs = ms[j] < max_workgroups ? ms[j] : max_workgroups;
-            jobs[j] = EncFwdJob{*p, xs[j], zs[j], saveds[j], ms[j], grid, wgs};
-            grid += wgs;
+            if (enc_narrow(*p)) {      // one wave per sample, a launch of its own
+                const int per_wg = TPB / 64, passes = (ms[j] + per_wg - 1) / per_wg;
+                NarrowJob nj = narrow_job(*p, blk, ms[j]);
+                nj.x = xs[j];
+                nj.z = blk == 2 ? zs[j] : nullptr;
+                nj.saved = saveds[j];
+                nj.wg_count = passes < max_workgroups ? passes : max_workgroups;
+                narrow[nn++] = nj;
+            } else {
+                const size_t need = sizeof(float) * (gm.cin * gm.hin + 7 * gm.cout * gm.hout + gm.psize_blk);
+                lds_w = need > lds_w ? need : lds_w;
+                const int wgs = ms[j] < max_workgroups ? ms[j] : max_workgroups;
+                wide[nw++] = EncFwdJob{*p, xs[j], zs[j], saveds[j], ms[j], grid_w, wgs};
+                grid_w += wgs;
+            }
         }
-        if (int rc = set_lds(enc_block_fwd_multi_kernel, lds, "encoder block forward")) return rc;
-        if (int rc = launch_checked([&] {
-                hipLaunchKernelGGL(enc_block_fwd_multi_kernel, dim3(grid), dim3(TPB), lds, (hipStream_t)stream, jobs[0], jobs[1], njobs,
-                                   blk);
-            }, "enc_block_fwd")) return rc;
+        // ONE launch: the wide jobs' workgroups first, the (first) narrow job's behind them; further narrow jobs on their own
+        auto narrow_lds = [](const NarrowJob& nj) {
+            return sizeof(float) * ((size_t)(TPB / 64) * nr_fwd_wave_floats(nj.cin, nj.hin, nj.cout, nj.hout) + nj.psize_blk);
+        };
+        if (nw) {
+            const bool ride = nn > 0;
+            const size_t lds = ride && narrow_lds(narrow[0]) > lds_w ? narrow_lds(narrow[0]) : lds_w;
+            const int grid = grid_w + (ride ? narrow[0].wg_count : 0);
+            if (int rc = set_lds(enc_block_fwd_multi_kernel, lds, "encoder block forward")) return rc;
+            if (int rc = launch_checked([&] {
+                    hipLaunchKernelGGL(enc_block_fwd_multi_kernel, dim3(grid), dim3(TPB), lds, (hipStream_t)stream, wide[0], wide[1], nw,
+                                       blk, narrow[0], ride ? grid_w : grid);
+                }, "enc_block_fwd")) return rc;
+        }
+        for (int k = nw ? 1 : 0; k < nn; ++k) {
+            const NarrowJob& nj = narrow[k];
+            const size_t lds_n = narrow_lds(nj);
+            if (int rc = set_lds(enc_narrow_fwd_kernel, lds_n, "narrow encoder block forward")) return rc;
+            if (int rc = launch_checked([&] {
+                    hipLaunchKernelGGL(enc_narrow_fwd_kernel, dim3(nj.wg_count), dim3(TPB), lds_n, (hipStream_t)stream, nj);
+                }, "enc_narrow_fwd")) return rc;
+        }
     }
     return 0;
 }
@@ -2421,9 +2958,10 @@ int sur_encoder_backward_multi(void* stream, int njobs, const sur_encoder_params
     if (split) {
         // one residual block per launch, last block first; every launch carries all jobs
         for (int blk = 2; blk >= 0; --blk) {
-            EncBlockJob jobs[3] = {};
-            size_t lds = 0;
-            int grid = 0;
+            EncBlockJob wide[3] = {};
+            NarrowJob narrow[3] = {};
+            size_t lds_w = 0;
+            int grid_w = 0, nw = 0, nn = 0;
             for (int j = 0; j < njobs; ++j) {
                 const sur_encoder_params* p = ps[j];
                 if (!xs[j] || !dzs[j] || ms[j] <= 0) return fail(-1, "sur_encoder_backward_multi: job %d: bad argument", j);
@@ -2433,19 +2971,48 @@ int sur_encoder_backward_multi(void* stream, int njobs, const sur_encoder_params
                 const EncBlockGeom gm = enc_block_geom(*p, blk);
                 if ((gm.cout * gm.hout) & 3 || ((gm.cin * gm.hin) & 3 && blk > 0))
                     return fail(-4, "sur_encoder_backward_multi: job %d: block %d is not float4-granular", j, blk);
-                const size_t base = sizeof(float) * (enc_block_act_floats(gm) + gm.psize_blk);
-                const int gl = (base + sizeof(float) * gm.psize_blk <= LDS_LIMIT) ? 1 : 0;
-                const size_t need = base + (gl ? sizeof(float) * gm.psize_blk : 0);
-                lds = need > lds ? need : lds;
-                const int wgs = ms[j] < row_counts[j] ? ms[j] : row_counts[j];
-                jobs[j] = EncBlockJob{*p, xs[j], dzs[j], saveds[j], workspaces[j], ms[j], row_bases[j], grid, wgs, gl};
-                grid += wgs;
+                if (enc_narrow(*p)) {       // one wave per sample, gradient accumulators per wave in LDS, a launch of its own
+                    const int per_wg = TPB / 64, passes = (ms[j] + per_wg - 1) / per_wg;
+                    NarrowJob nj = narrow_job(*p, blk, ms[j]);
+                    nj.x = xs[j];
+                    nj.dz = dzs[j];
+                    nj.saved = const_cast<float*>(saveds[j]);
+                    nj.ws = workspaces[j];
+                    nj.wg_count = passes < row_counts[j] ? passes : row_counts[j];
+                    nj.row_stride = psize_of<SUR_ENC_NPARAM>(p->size);
+                    nj.rows = p->partial + (size_t)row_bases[j] * nj.row_stride + gm.param_off;
+                    narrow[nn++] = nj;
+                } else {
+                    const size_t base = sizeof(float) * (enc_block_act_floats(gm) + gm.psize_blk);
+                    const int gl = (base + sizeof(float) * gm.psize_blk <= LDS_LIMIT) ? 1 : 0;
+                    const size_t need = base + (gl ? sizeof(float) * gm.psize_blk : 0);
+                    lds_w = need > lds_w ? need : lds_w;
+                    const int wgs = ms[j] < row_counts[j] ? ms[j] : row_counts[j];
+                    wide[nw++] = EncBlockJob{*p, xs[j], dzs[j], saveds[j], workspaces[j], ms[j], row_bases[j], grid_w, wgs, gl};
+                    grid_w += wgs;
+                }
             }
-            if (int rc = set_lds(enc_block_bwd_multi_kernel, lds, "encoder block backward")) return rc;
-            if (int rc = launch_checked([&] {
-                    hipLaunchKernelGGL(enc_block_bwd_multi_kernel, dim3(grid), dim3(TPB), lds, (hipStream_t)stream, jobs[0], jobs[1],
-                                       jobs[2], njobs, blk);
-                }, "enc_block_bwd")) return rc;
+            auto narrow_lds = [](const NarrowJob& nj) {
+                return sizeof(float) * ((size_t)(TPB / 64) * nr_bwd_wave_floats(nj.cin, nj.hin, nj.cout, nj.hout, nj.psize_blk) + nj.psize_blk);
+            };
+            if (nw) {      // ONE launch: the wide jobs' workgroups first, the (first) narrow job's behind them
+                const bool ride = nn > 0;
+                const size_t lds = ride && narrow_lds(narrow[0]) > lds_w ? narrow_lds(narrow[0]) : lds_w;
+                const int grid = grid_w + (ride ? narrow[0].wg_count : 0);
+                if (int rc = set_lds(enc_block_bwd_multi_kernel, lds, "encoder block backward")) return rc;
+                if (int rc = launch_checked([&] {
+                        hipLaunchKernelGGL(enc_block_bwd_multi_kernel, dim3(grid), dim3(TPB), lds, (hipStream_t)stream, wide[0], wide[1],
+                                           wide[2], nw, blk, narrow[0], ride ? grid_w : grid);
+                    }, "enc_block_bwd")) return rc;
+            }
+            for (int k = nw ? 1 : 0; k < nn; ++k) {
+                const NarrowJob& nj = narrow[k];
+                const size_t lds_n = narrow_lds(nj);
+                if (int rc = set_lds(enc_narrow_bwd_kernel, lds_n, "narrow encoder block backward")) return rc;
+                if (int rc = launch_checked([&] {
+                        hipLaunchKernelGGL(enc_narrow_bwd_kernel, dim3(nj.wg_count), dim3(TPB), lds_n, (hipStream_t)stream, nj);
+                    }, "enc_narrow_bwd")) return rc;
+            }
         }
         return 0;
     }
