@@ -67,6 +67,18 @@ __device__ __forceinline__ float dpp_rot(float v) {
     return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, false));
 }
 
+// v + (v of lane ^ 16) / (v of lane ^ 32): the swap instructions exchange the odd rows of 16 (the upper 32 lanes) of their first
+// operand with the even rows (the lower 32 lanes) of the second; on two copies of v that leaves [r0 r0 r2 r2] and [r1 r1 r3 r3]
+typedef unsigned swap_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float swap_add16(float v) {
+    const swap_u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float swap_add32(float v) {
+    const swap_u2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 // sums of a and b over aligned groups of `lpc` lanes (16, 32 or 64); every lane gets both totals
 __device__ __forceinline__ void group_sum2(float& a, float& b, int lpc) {
     a += dpp_rot<0x128>(a);  // row_ror:8
@@ -77,13 +89,13 @@ __device__ __forceinline__ void group_sum2(float& a, float& b, int lpc) {
     b += dpp_rot<0x122>(b);
     a += dpp_rot<0x121>(a);  // row_ror:1
     b += dpp_rot<0x121>(b);
-    if (lpc >= 32) {
-        a += __shfl_xor(a, 16, 64);
-        b += __shfl_xor(b, 16, 64);
+    if (lpc >= 32) {   // lane ^ 16: v_permlane16_swap of a value with itself (gfx950) -- same operands as a ds_bpermute exchange,
+        a = swap_add16(a);   // without the trip through the LDS crossbar
+        b = swap_add16(b);
     }
-    if (lpc >= 64) {
-        a += __shfl_xor(a, 32, 64);
-        b += __shfl_xor(b, 32, 64);
+    if (lpc >= 64) {   // lane ^ 32
+        a = swap_add32(a);
+        b = swap_add32(b);
     }
 }
 
@@ -273,6 +285,22 @@ template <int K>
 __device__ void conv_bwd_data(const float* dout, int cout, int hin, const float* W, int cin, int stride, int pad,
                               float* din, bool accumulate, WaveSet ws = WaveSet{0, 1 << 20}, bool sync = true) {
     const int hout = hin / stride;
+    if (cout == 1 && stride == 1) {
+        // a K-tap stencil per input channel: cin * K MACs per position on the VALU.  (As a gather-GEMM the single output
+        // channel fills one of the four K slots of every MFMA step: 7 k cycles for the decoder's 7-tap layer at N = 256.)
+        const int wid = threadIdx.x >> 6, nwg = blockDim.x >> 6;
+        const int nw = ws.cnt < nwg ? ws.cnt : nwg, t0 = threadIdx.x - 64 * ws.lo;
+        if (wid >= ws.lo && wid < ws.lo + nw)
+            for (int it = t0; it < cin * hin; it += 64 * nw) {
+                const int ci = it / hin, j = it - ci * hin;
+                float acc = accumulate ? din[it] : 0.0f;
+#pragma unroll
+                for (int k = 0; k < K; ++k) acc = fmaf(W[ci * K + k], dout[wrapi(j - k + pad, hin)], acc);
+                din[it] = acc;
+            }
+        if (sync) __syncthreads();
+        return;
+    }
     const GemmSeg seg[1] = {{W, K, cin * K, dout, hout, cout}};  // A[m=ci][c=o][tap] = W[(o*cin + ci)*K + tap]
     gemm_taps<K, 1>(ws, sync, cin, hin, seg,
                     [&](int, int tap, int j) {
@@ -285,10 +313,59 @@ __device__ void conv_bwd_data(const float* dout, int cout, int hin, const float*
 }
 
 // gW[o][ci][k] += sum_p dout[o][p] * in[ci][(p*stride + k - pad) mod hin];  gb[o] += sum_p dout[o][p]
+// `scratch` (LDS, scratch_floats floats, not aliasing any operand): lets the single-output-channel case run as an MFMA tile.
 template <int K>
 __device__ void conv_bwd_weight(const float* dout, int cout, const float* in, int cin, int hin, int stride, int pad,
-                                float* gW, float* gb, WaveSet ws = WaveSet{0, 1 << 20}, bool sync = true) {
+                                float* gW, float* gb, WaveSet ws = WaveSet{0, 1 << 20}, bool sync = true, float* scratch = nullptr,
+                                int scratch_floats = 0) {
     const int hout = hin / stride, ncols = cin * K;
+    if (cout == 1 && stride == 1 && K <= 16 && cin < 16 && (cin + 1) * K <= 64 && scratch_floats >= 64 && (hin & 3) == 0) {
+        // gW[ci][k] = sum_j dout[(j - k + pad) mod hin] * in[ci][j]: ONE tile with the taps as rows, the input channels (and
+        // a column of ones: the bias) as columns, reduced over the input positions four at a time -- the positions split
+        // over the waves, their partial tiles added in wave order through `scratch`.  hin / 16 MFMA steps per wave where the
+        // 16-lane dot products below took 13 k cycles for the decoder's 7-tap layer at N = 256.
+        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nwg = blockDim.x >> 6;
+        const int r = lane & 15, q = lane >> 4;
+        int nw = ws.cnt < nwg ? ws.cnt : nwg;
+        if (nw > scratch_floats >> 6) nw = scratch_floats >> 6;
+        const int steps = hin >> 2, per = (steps + nw - 1) / nw;
+        if (wid >= ws.lo && wid < ws.lo + nw) {
+            const int wv = wid - ws.lo;
+            const bool a_ok = r < K, b_in = r < cin;
+            const float b_const = (r == cin && gb) ? 1.0f : 0.0f;
+            const float* brow = in + (b_in ? r : 0) * hin;
+            const int shift = pad - (a_ok ? r : 0);
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            const int s1 = (wv + 1) * per < steps ? (wv + 1) * per : steps;
+            int st = wv * per;
+            for (; st + 2 <= s1; st += 2) {
+                const int ja = 4 * st + q, jb = ja + 4;
+                const float a0 = dout[wrapi(ja + shift, hin)], b0 = b_in ? brow[ja] : b_const;
+                const float a1 = dout[wrapi(jb + shift, hin)], b1 = b_in ? brow[jb] : b_const;
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_ok ? a0 : 0.f, b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_ok ? a1 : 0.f, b1, acc1, 0, 0, 0);
+            }
+            if (st < s1) {
+                const int ja = 4 * st + q;
+                const float a0 = dout[wrapi(ja + shift, hin)], b0 = b_in ? brow[ja] : b_const;
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_ok ? a0 : 0.f, b0, acc0, 0, 0, 0);
+            }
+            if (r <= cin) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (4 * q + i < K) scratch[wv * 64 + r * K + 4 * q + i] = acc0[i] + acc1[i];
+            }
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < ncols + (gb ? 1 : 0); t += blockDim.x) {
+            float v = 0.0f;
+            for (int wv = 0; wv < nw; ++wv) v += scratch[wv * 64 + t];
+            if (t < ncols) gW[t] += v;
+            else gb[0] += v;      // t = cin * K: row 0 of the ones column
+        }
+        if (sync) __syncthreads();
+        return;
+    }
     if (cout == 1) {
         // ncols + 1 dot products of length hout (the weight taps and the bias): one per 16-lane group, positions
         // strided over the group's lanes, partial sums folded with DPP row rotations.  (One thread per dot product
@@ -380,13 +457,22 @@ __device__ void deconv_bwd_data(const float* dout, int cout, int hin, const floa
 __device__ void deconv_bwd_weight(const float* dout, int cout, const float* in, int cin, int hin, float* gW, float* gb,
                                   WaveSet ws = WaveSet{0, 1 << 20}, bool sync = true) {
     const int hout = 2 * hin, ncols = cout * 3;
-    for (int o = threadIdx.x; o < cout; o += blockDim.x) {
-        float a0 = 0.0f, a1 = 0.0f;
-        for (int j = 0; j < hout; j += 2) {
-            a0 += dout[o * hout + j];
-            a1 += dout[o * hout + j + 1];
+    {
+        // bias gradient: one 16-lane group per output channel, positions strided over the group's lanes.  (One thread per
+        // channel with a serial loop over hout was 16 k cycles at hout = 256 -- a fifth of the decoder backward -- all of
+        // it in the wave that then starts on the first tile of the GEMM below.)
+        const int group = threadIdx.x >> 4, gl = threadIdx.x & 15, ngroups = blockDim.x >> 4;
+        for (int o0 = 0; o0 < cout; o0 += ngroups) {
+            const int o = o0 + group;
+            float a0 = 0.0f, a1 = 0.0f;
+            if (o < cout)
+                for (int j = gl; j < hout; j += 32) {
+                    a0 += dout[o * hout + j];
+                    if (j + 16 < hout) a1 += dout[o * hout + j + 16];
+                }
+            group_sum2(a0, a1, 16);
+            if (gl == 0 && o < cout) gb[o] += a0 + a1;
         }
-        gb[o] += a0 + a1;
     }
     struct St { const float* row; int off; };
     gemm_pos(ws, sync, cin, ncols, hin, in, hin,
@@ -709,28 +795,36 @@ __host__ __device__ inline bool enc_narrow(const sur_encoder_params& p) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    \
     } while (0)
 
-// totals of a and b over the whole wave, returned wave-uniform (SGPRs): four rotations inside the rows of 16 lanes, two DPP row
-// broadcasts across the rows, one v_readlane -- no trip through the LDS crossbar (group_sum2's 16- and 32-lane steps are
-// ds_bpermute round trips; a wave that owns a whole sample has nothing to hide them behind)
-template <int CTRL, int ROWS>
-__device__ __forceinline__ float nr_bcast_add(float v) {
-    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROWS, 0xf, false));
+// Totals over the whole wave of M (4 or 8) per-lane values, returned wave-uniform (SGPRs).  A halving butterfly: in a stage two
+// lanes that differ in one bit of the lane id split a PAIR of values between them -- each keeps one, hands the other over and
+// adds what it receives -- so a lane carries half as many values afterwards; M values cost ~M exchanges instead of 6 M, in six
+// dependent stages instead of 6 M / 2 (a wave that owns a whole sample has nothing to hide that chain behind; LayerNorm sums
+// were half of the narrow kernels' instructions).  Lane bits 0 and 1 by DPP quad permutes, bit 4 by v_permlane16_swap (which
+// IS the keep-one-hand-one-over exchange between even and odd rows of 16), then plain all-reduce steps on the one value left:
+// bits 3, 2 by row rotations, bit 5 by v_permlane32_swap.  Every lane ends up with the total of the value its bits (4,1,0)
+// name; v_readlane hands them out.
+template <int CTRL>
+__device__ __forceinline__ float nr_halve(bool upper, float lo, float hi) {
+    return (upper ? hi : lo) + dpp_rot<CTRL>(upper ? lo : hi);
 }
-__device__ __forceinline__ void nr_wave_sum2(float& a, float& b) {
-    a += dpp_rot<0x128>(a);  // row_ror:8
-    b += dpp_rot<0x128>(b);
-    a += dpp_rot<0x124>(a);  // row_ror:4
-    b += dpp_rot<0x124>(b);
-    a += dpp_rot<0x122>(a);  // row_ror:2
-    b += dpp_rot<0x122>(b);
-    a += dpp_rot<0x121>(a);  // row_ror:1
-    b += dpp_rot<0x121>(b);
-    a = nr_bcast_add<0x142, 0xa>(a);   // row_bcast:15 into rows 1 and 3
-    b = nr_bcast_add<0x142, 0xa>(b);
-    a = nr_bcast_add<0x143, 0xc>(a);   // row_bcast:31 into rows 2 and 3: lane 63 holds the total
-    b = nr_bcast_add<0x143, 0xc>(b);
-    a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), 63));
-    b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b), 63));
+template <int M>
+__device__ __forceinline__ void nr_wave_totals(float (&v)[M], int lane) {
+    static_assert(M == 4 || M == 8, "two or four channels, two sums each");
+    const bool b0 = lane & 1, b1 = lane & 2;
+    float w[M / 2], x[M / 4];
+#pragma unroll
+    for (int i = 0; i < M / 2; ++i) w[i] = nr_halve<0xB1>(b0, v[2 * i], v[2 * i + 1]);     // quad_perm:[1,0,3,2]
+#pragma unroll
+    for (int i = 0; i < M / 4; ++i) x[i] = nr_halve<0x4E>(b1, w[2 * i], w[2 * i + 1]);     // quad_perm:[2,3,0,1]
+    // rows 1, 3 of the first operand <-> rows 0, 2 of the second: even rows collect x[0], odd rows x[M / 4 - 1]
+    const swap_u2 r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(x[0]), __float_as_uint(x[M / 4 - 1]), false, false);
+    float t = __uint_as_float(r16[0]) + __uint_as_float(r16[1]);
+    t += dpp_rot<0x128>(t);  // row_ror:8
+    t += dpp_rot<0x124>(t);  // row_ror:4: with the step before, the four lanes of the row that share bits 0 and 1
+    t = swap_add32(t);
+#pragma unroll
+    for (int m = 0; m < M; ++m)
+        v[m] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t), (m & 3) + (M == 8 ? 16 * (m >> 2) : 0)));
 }
 
 // A lane's values of a [C][H] activation: channels c < TC, positions lane + 64 e, e < TE.  TC / TE are compile-time bounds
@@ -801,24 +895,30 @@ template <int TC, int TE>
 __device__ __forceinline__ void nr_ln_fwd(const NrTile<TC, TE>& x, int C, int H, const float* gamma, const float* beta, bool silu,
                                           int lane, NrTile<TC, TE>& y) {
     const float inv_h = 1.0f / H;
+    float a[TC][TE], st[2 * TC];
 #pragma unroll
     for (int c = 0; c < TC; ++c) {
-        float a[TE], s = 0.0f, ss = 0.0f;
+        float s = 0.0f, ss = 0.0f;
 #pragma unroll
         for (int e = 0; e < TE; ++e) {
             const bool live = c < C && lane + 64 * e < H;
             const float v = x.v[c][e];
-            a[e] = live ? (silu ? v * sigmoid_(v) : v) : 0.0f;
-            s += a[e];
-            ss = fmaf(a[e], a[e], ss);
+            a[c][e] = live ? (silu ? v * sigmoid_(v) : v) : 0.0f;
+            s += a[c][e];
+            ss = fmaf(a[c][e], a[c][e], ss);
         }
-        nr_wave_sum2(s, ss);
-        const float mean = s * inv_h;
-        const float rstd = rsqrtf(fmaxf(fmaf(-mean, mean, ss * inv_h), 0.0f) + LN_EPS);
+        st[2 * c] = s;
+        st[2 * c + 1] = ss;
+    }
+    nr_wave_totals(st, lane);
+#pragma unroll
+    for (int c = 0; c < TC; ++c) {
+        const float mean = st[2 * c] * inv_h;
+        const float rstd = rsqrtf(fmaxf(fmaf(-mean, mean, st[2 * c + 1] * inv_h), 0.0f) + LN_EPS);
 #pragma unroll
         for (int e = 0; e < TE; ++e) {
             const int p = lane + 64 * e;
-            y.v[c][e] = (c < C && p < H) ? fmaf((a[e] - mean) * rstd, gamma[p], beta[p]) : 0.0f;
+            y.v[c][e] = (c < C && p < H) ? fmaf((a[c][e] - mean) * rstd, gamma[p], beta[p]) : 0.0f;
         }
     }
 }
@@ -828,47 +928,57 @@ template <int TC, int TE>
 __device__ __forceinline__ void nr_ln_bwd(const NrTile<TC, TE>& dout, const NrTile<TC, TE>& pre, int C, int H, const float* gamma,
                                           bool silu, int lane, NrTile<TC, TE>& dpre, float* ggamma, float* gbeta) {
     const float inv_h = 1.0f / H;
-    float gg[TE], gb[TE];
-#pragma unroll
-    for (int e = 0; e < TE; ++e) gg[e] = gb[e] = 0.0f;
+    float y[TC][TE], dxh[TC][TE], st[2 * TC], rstd[TC];
 #pragma unroll
     for (int c = 0; c < TC; ++c) {
-        float y[TE], dxh[TE], s = 0.0f, ss = 0.0f;
+        float s = 0.0f, ss = 0.0f;
 #pragma unroll
         for (int e = 0; e < TE; ++e) {
             const int p = lane + 64 * e;
             const bool live = c < C && p < H;
             const float v = pre.v[c][e];
-            y[e] = live ? (silu ? v * sigmoid_(v) : v) : 0.0f;
-            dxh[e] = live ? dout.v[c][e] * gamma[p] : 0.0f;
-            s += y[e];
-            ss = fmaf(y[e], y[e], ss);
+            y[c][e] = live ? (silu ? v * sigmoid_(v) : v) : 0.0f;
+            dxh[c][e] = live ? dout.v[c][e] * gamma[p] : 0.0f;
+            s += y[c][e];
+            ss = fmaf(y[c][e], y[c][e], ss);
         }
-        nr_wave_sum2(s, ss);
-        const float mean = s * inv_h;
-        const float rstd = rsqrtf(fmaxf(fmaf(-mean, mean, ss * inv_h), 0.0f) + LN_EPS);
+        st[2 * c] = s;
+        st[2 * c + 1] = ss;
+    }
+    nr_wave_totals(st, lane);
+#pragma unroll
+    for (int c = 0; c < TC; ++c) {
+        const float mean = st[2 * c] * inv_h;
+        rstd[c] = rsqrtf(fmaxf(fmaf(-mean, mean, st[2 * c + 1] * inv_h), 0.0f) + LN_EPS);
         float m1 = 0.0f, m2 = 0.0f;
 #pragma unroll
         for (int e = 0; e < TE; ++e) {
             const bool live = c < C && lane + 64 * e < H;
-            y[e] = live ? (y[e] - mean) * rstd : 0.0f;     // xhat
-            m1 += dxh[e];
-            m2 = fmaf(dxh[e], y[e], m2);
+            y[c][e] = live ? (y[c][e] - mean) * rstd[c] : 0.0f;     // xhat
+            m1 += dxh[c][e];
+            m2 = fmaf(dxh[c][e], y[c][e], m2);
         }
-        nr_wave_sum2(m1, m2);
-        m1 *= inv_h;
-        m2 *= inv_h;
+        st[2 * c] = m1;
+        st[2 * c + 1] = m2;
+    }
+    nr_wave_totals(st, lane);
+    float gg[TE], gb[TE];
+#pragma unroll
+    for (int e = 0; e < TE; ++e) gg[e] = gb[e] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < TC; ++c) {
+        const float m1 = st[2 * c] * inv_h, m2 = st[2 * c + 1] * inv_h;
 #pragma unroll
         for (int e = 0; e < TE; ++e) {
             const bool live = c < C && lane + 64 * e < H;
-            float dy = rstd * (dxh[e] - m1 - y[e] * m2);
+            float dy = rstd[c] * (dxh[c][e] - m1 - y[c][e] * m2);
             if (silu) {
                 const float v = pre.v[c][e], sg = sigmoid_(v);
                 dy *= sg * (1.0f + v * (1.0f - sg));
             }
             dpre.v[c][e] = live ? dy : 0.0f;
             if (live) {
-                gg[e] = fmaf(dout.v[c][e], y[e], gg[e]);
+                gg[e] = fmaf(dout.v[c][e], y[c][e], gg[e]);
                 gb[e] += dout.v[c][e];
             }
         }
@@ -1851,13 +1961,16 @@ template <typename StoreP0, typename StoreH>
 __device__ void decoder_backward(const sur_chunk_params& p, const StepLayout& L, const float* const* w, float* const* g,
                                  StoreP0 late_p0, StoreH late_h) {
     const int n = L.n;
-    conv_bwd_weight<5>(L.gA, 1, L.a2, 1, n, 1, 2, g[SUR_ST_CV3_W], g[SUR_ST_CV3_B], all_waves(), false);
+    // single-channel gradients fill the first n floats of gA: the rest of the buffer is the weight gradients' scratch
+    float* const wg_scratch = L.gA + n;
+    const int wg_floats = step_max_act(p) - n;
+    conv_bwd_weight<5>(L.gA, 1, L.a2, 1, n, 1, 2, g[SUR_ST_CV3_W], g[SUR_ST_CV3_B], all_waves(), false, wg_scratch, wg_floats);
     STAMP(12);
     conv_bwd_data<5>(L.gA, 1, n, w[SUR_ST_CV3_W], 1, 1, 2, L.gB, false);
     STAMP(13);
     act_ln_bwd(L.gB, L.p2, 1, n, w[SUR_ST_LN2_W], true, L.gA, L.a2, g[SUR_ST_LN2_W], g[SUR_ST_LN2_B]);
     STAMP(14);
-    conv_bwd_weight<7>(L.gA, 1, L.a1, p.c_mid, n, 1, 3, g[SUR_ST_CV2_W], g[SUR_ST_CV2_B], all_waves(), false);
+    conv_bwd_weight<7>(L.gA, 1, L.a1, p.c_mid, n, 1, 3, g[SUR_ST_CV2_W], g[SUR_ST_CV2_B], all_waves(), false, wg_scratch, wg_floats);
     STAMP(15);
     conv_bwd_data<7>(L.gA, 1, n, w[SUR_ST_CV2_W], p.c_mid, 1, 3, L.gB, false);
     STAMP(16);
