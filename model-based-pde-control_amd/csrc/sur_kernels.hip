@@ -181,6 +181,7 @@ __device__ __forceinline__ void gemm_taps(WaveSet ws, bool sync, int M, int N, c
                     const float* ap = S.a + m_safe * S.a_sm + tap;
                     const float* bp = S.b + (cidx >= 0 ? cidx : 0);
                     const bool b_ok = cidx >= 0;
+                    if (__builtin_amdgcn_ballot_w64(b_ok) == 0) continue;   // this tap reaches none of the tile's columns
                     int c0 = 0;
                     for (; c0 + 8 <= S.cin; c0 += 8) {  // 2 MFMAs per trip on independent accumulators
                         const float a0 = ap[(c0 + q) * S.a_sc], b0 = bp[(c0 + q) * S.b_sc];
@@ -285,19 +286,46 @@ template <int K>
 __device__ void conv_bwd_data(const float* dout, int cout, int hin, const float* W, int cin, int stride, int pad,
                               float* din, bool accumulate, WaveSet ws = WaveSet{0, 1 << 20}, bool sync = true) {
     const int hout = hin / stride;
-    if (cout == 1 && stride == 1) {
-        // a K-tap stencil per input channel: cin * K MACs per position on the VALU.  (As a gather-GEMM the single output
-        // channel fills one of the four K slots of every MFMA step: 7 k cycles for the decoder's 7-tap layer at N = 256.)
+    if (cout == 1 && stride == 1 && cin == 1) {   // one K-tap stencil: a position per thread on the VALU
         const int wid = threadIdx.x >> 6, nwg = blockDim.x >> 6;
-        const int nw = ws.cnt < nwg ? ws.cnt : nwg, t0 = threadIdx.x - 64 * ws.lo;
+        const int nw = ws.cnt < nwg ? ws.cnt : nwg;
         if (wid >= ws.lo && wid < ws.lo + nw)
-            for (int it = t0; it < cin * hin; it += 64 * nw) {
-                const int ci = it / hin, j = it - ci * hin;
-                float acc = accumulate ? din[it] : 0.0f;
+            for (int j = threadIdx.x - 64 * ws.lo; j < hin; j += 64 * nw) {
+                float acc = accumulate ? din[j] : 0.0f;
 #pragma unroll
-                for (int k = 0; k < K; ++k) acc = fmaf(W[ci * K + k], dout[wrapi(j - k + pad, hin)], acc);
-                din[it] = acc;
+                for (int k = 0; k < K; ++k) acc = fmaf(W[k], dout[wrapi(j - k + pad, hin)], acc);
+                din[j] = acc;
             }
+        if (sync) __syncthreads();
+        return;
+    }
+    if (cout == 1 && stride == 1 && cin <= 16 && K <= 8 && (hin & 15) == 0) {
+        // din[ci][j] = sum_k W[ci][k] * dout[(j - k + pad) mod hin]: the TAPS are the reduction dimension -- rows = input
+        // channels, columns = 16 positions, ceil(K / 4) MFMA steps per tile.  (The generic gather-GEMM reduces over
+        // (output channel, tap) with the channels four at a time: with one output channel K steps per tile, three of
+        // four k-slots empty -- 7 k cycles for the decoder's 7-tap layer at N = 256.)
+        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nwg = blockDim.x >> 6;
+        const int nw = ws.cnt < nwg ? ws.cnt : nwg;
+        if (wid >= ws.lo && wid < ws.lo + nw) {
+            const int r = lane & 15, q = lane >> 4;
+            const float w0 = (r < cin && q < K) ? W[r * K + q] : 0.0f;
+            const float w1 = (r < cin && 4 + q < K) ? W[r * K + 4 + q] : 0.0f;
+            for (int t = wid - ws.lo; t < (hin >> 4); t += nw) {
+                const int j = 16 * t + r;
+                const float d0 = q < K ? dout[wrapi(j - q + pad, hin)] : 0.0f;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0, d0, acc, 0, 0, 0);
+                if (K > 4) {
+                    const float d1 = 4 + q < K ? dout[wrapi(j - 4 - q + pad, hin)] : 0.0f;
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w1, d1, acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int ci = 4 * q + i;
+                    if (ci < cin) din[ci * hin + j] = accumulate ? din[ci * hin + j] + acc[i] : acc[i];
+                }
+            }
+        }
         if (sync) __syncthreads();
         return;
     }
@@ -430,13 +458,19 @@ __device__ void deconv_fwd(const float* in, int cin, int hin, const float* W, co
                            float* out, WaveSet ws = WaveSet{0, 1 << 20}, bool sync = true) {
     const int hout = 2 * hin;
     const GemmSeg seg[1] = {{W, 3, cout * 3, in, hin, cin}};  // A[m=o][c=ci][tap] = W[(ci*cout + o)*3 + tap]
+    // An even output position takes the middle tap only, an odd one the outer two.  With the GEMM's columns in output
+    // order every tile of 16 holds both parities and issues all three taps, half of them on zeros; with the even positions
+    // in the first hin columns and the odd ones behind them (hin a multiple of 16) a tile is of one parity and gemm_taps
+    // skips the taps that reach none of its columns: 1 or 2 tap passes per tile instead of 3.
+    const bool sorted = (hin & 15) == 0;
+    auto pos = [&](int n) { return sorted ? (n < hin ? 2 * n : 2 * (n - hin) + 1) : n; };
     gemm_taps<3, 1>(ws, sync, cout, hout, seg,
-                    [&](int, int tap, int j) {
-                        const int t = j + 1 - tap;
+                    [&](int, int tap, int n) {
+                        const int t = pos(n) + 1 - tap;
                         return (t < 0 || (t & 1) || (t >> 1) >= hin) ? -1 : (t >> 1);
                     },
-                    [&](int m, int j, float v) {
-                        if (m < cout) out[m * hout + j] = v + bias[m];
+                    [&](int m, int n, float v) {
+                        if (m < cout) out[m * hout + pos(n)] = v + bias[m];
                     });
 }
 
