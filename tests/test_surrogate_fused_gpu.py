@@ -304,7 +304,10 @@ def test_graphed_step_leaves_eager_backward_untouched(dev):
 
 def test_adam_inside_the_flush_launch_matches_torch_adam(dev):
     """Three graph-replayed optimizer steps (Adam applied by the gradient-reduction launch) against three eager steps
-    with torch.optim.Adam on the same fused kernels: same gradients, so the parameters must agree to Adam's rounding."""
+    with torch.optim.Adam on the same fused kernels.  The two schedules sum the per-workgroup gradient rows in different
+    orders (pipelined chunks + folded rows vs one launch set), so a gradient element differs by up to GRAD_TOL = 2e-4 of
+    its tensor's scale (conftest.check_grads); Adam's update lr * m / (sqrt(v) + eps) is homogeneous of degree 0 in the
+    gradients, so that relative noise passes straight into the update: <= lr * GRAD_TOL per step, 3 steps."""
     from pdecontrol.surrogates import ops
     from pdecontrol.surrogates.bench_tbptt import build_module, synthetic_batch
     from pdecontrol.surrogates.graph_step import GraphedTBPTTStep
@@ -325,7 +328,8 @@ def test_adam_inside_the_flush_launch_matches_torch_adam(dev):
         g.step()
         torch.cuda.synchronize(dev)
         for (name, p), q in zip(m.surrogate.named_parameters(), ref.surrogate.parameters()):
-            np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), rtol=2e-5, atol=2e-7, err_msg=name)
+            np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), rtol=2e-5, atol=3 * ref.lr * 2e-4,
+                                       err_msg=name)
     finally:
         ops.reset_fused()
 
