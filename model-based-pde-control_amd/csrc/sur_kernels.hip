@@ -2044,18 +2044,22 @@ __device__ void cell_dh_gemm(const sur_chunk_params& p, const StepLayout& L, con
 
 // Cell backward, non-recurrent part for one (step, sample): dx [ca][hq] = sum_g Wx_g^T * dG_g and the LSTM weight /
 // bias gradients dG_g x {x, h_in}.  dx on the first wave, the weight-gradient tiles on the others.
-__device__ void cell_wgrad_gemms(const sur_chunk_params& p, const StepLayout& L, const float* const* w, float* const* g) {
-    const int s = p.cs * p.hq, nwg = blockDim.x >> 6, cs = p.cs, ca = p.ca, hq = p.hq;
-    const int gate_stride = (int)(w[SUR_ST_WXF] - w[SUR_ST_WXI]);
+// `hs`: floats between consecutive rows of L.x, L.h and L.dgates (>= hq).  With hs = hq = 64 the sixteen tile rows a GEMM operand
+// is gathered from start in the same LDS bank (SQ_LDS_BANK_CONFLICT was 79 % of the LDS-active cycles of this kernel);
+// hs = hq + 4 staggers them by four banks and keeps rows 16-byte aligned.
+__device__ void cell_wgrad_gemms(const sur_chunk_params& p, const StepLayout& L, const float* const* w, float* const* g, int hs) {
+    const int s = p.cs * hs, nwg = blockDim.x >> 6, cs = p.cs, ca = p.ca, hq = p.hq;
+    const int gate_stride = (int)(w[SUR_ST_WXF] - w[SUR_ST_WXI]);     // between the gates' Wx as staged (cell_wgrad_kernel: back to back)
+    const int ggate_stride = (int)(g[SUR_ST_WXF] - g[SUR_ST_WXI]);    // between the gates' accumulators (parameter order)
     const WaveSet w_dx = nwg >= 4 ? WaveSet{0, 1} : all_waves();
     const WaveSet w_gw = nwg >= 4 ? WaveSet{1, nwg - 1} : all_waves();
     auto tap_col = [&](int, int tap, int j) { return wrapi(j - tap + 1, hq); };
     {
         const float* wx = w[SUR_ST_WXI];
-        const GemmSeg sx[4] = {{wx, 3, ca * 3, L.dgates, hq, cs},
-                               {wx + gate_stride, 3, ca * 3, L.dgates + s, hq, cs},
-                               {wx + 2 * gate_stride, 3, ca * 3, L.dgates + 2 * s, hq, cs},
-                               {wx + 3 * gate_stride, 3, ca * 3, L.dgates + 3 * s, hq, cs}};
+        const GemmSeg sx[4] = {{wx, 3, ca * 3, L.dgates, hs, cs},
+                               {wx + gate_stride, 3, ca * 3, L.dgates + s, hs, cs},
+                               {wx + 2 * gate_stride, 3, ca * 3, L.dgates + 2 * s, hs, cs},
+                               {wx + 3 * gate_stride, 3, ca * 3, L.dgates + 3 * s, hs, cs}};
         float* dxp = L.dx;
         gemm_taps<3, 4>(w_dx, false, ca, hq, sx, tap_col, [&](int m, int j, float v) {
             if (m < ca) dxp[m * hq + j] = v;
@@ -2066,25 +2070,25 @@ __device__ void cell_wgrad_gemms(const sur_chunk_params& p, const StepLayout& L,
         float* gx = g[SUR_ST_WXI];
         const float* xin = L.x;
         const int ncols = ca * 3;
-        gemm_pos(w_gw, false, 4 * cs, ncols, hq, L.dgates, hq,
-                 [&](int n) { const int ci = n / 3, k = n - ci * 3; return St{xin + ci * hq, k - 1}; },
+        gemm_pos(w_gw, false, 4 * cs, ncols, hq, L.dgates, hs,
+                 [&](int n) { const int ci = n / 3, k = n - ci * 3; return St{xin + ci * hs, k - 1}; },
                  [&](const St& st, int pp) { return st.row[wrapi(pp + st.off, hq)]; },
                  [&](int m, int n, float v) {
                      if (m < 4 * cs && n < ncols) {
                          const int gt = m / cs, o = m - gt * cs;
-                         gx[gt * gate_stride + o * ncols + n] += v;
+                         gx[gt * ggate_stride + o * ncols + n] += v;
                      }
                  });
         float* gh = g[SUR_ST_WHI];
         const float* hin_ = L.h;
         const int ncols_h = cs * 3;
-        gemm_pos(w_gw, false, 4 * cs, ncols_h, hq, L.dgates, hq,
-                 [&](int n) { const int ci = n / 3, k = n - ci * 3; return St{hin_ + ci * hq, k - 1}; },
+        gemm_pos(w_gw, false, 4 * cs, ncols_h, hq, L.dgates, hs,
+                 [&](int n) { const int ci = n / 3, k = n - ci * 3; return St{hin_ + ci * hs, k - 1}; },
                  [&](const St& st, int pp) { return st.row[wrapi(pp + st.off, hq)]; },
                  [&](int m, int n, float v) {
                      if (m < 4 * cs && n < ncols_h) {
                          const int gt = m / cs, o = m - gt * cs;
-                         gh[gt * gate_stride + o * ncols_h + n] += v;
+                         gh[gt * ggate_stride + o * ncols_h + n] += v;
                      }
                  });
         // bias gradients: one 16-lane group per (gate, channel) row of dG
@@ -2095,13 +2099,13 @@ __device__ void cell_wgrad_gemms(const sur_chunk_params& p, const StepLayout& L,
             float a0 = 0.0f, a1 = 0.0f;
             if (r < 4 * cs)
                 for (int pp = gl; pp < hq; pp += 32) {
-                    a0 += L.dgates[r * hq + pp];
-                    if (pp + 16 < hq) a1 += L.dgates[r * hq + pp + 16];
+                    a0 += L.dgates[r * hs + pp];
+                    if (pp + 16 < hq) a1 += L.dgates[r * hs + pp + 16];
                 }
             group_sum2(a0, a1, 16);
             if (gl == 0 && r < 4 * cs) {
                 const int gt = r / cs, o = r - gt * cs;
-                gbx[gt * gate_stride + o] += a0 + a1;
+                gbx[gt * ggate_stride + o] += a0 + a1;
             }
         }
     }
@@ -2135,7 +2139,7 @@ __host__ __device__ inline int cell_bwd_act_floats(const sur_chunk_params& p) {
     return 2 * 5 * s + 4 * s + 4 * s;
 }
 __host__ __device__ inline int cell_wgrad_act_floats(const sur_chunk_params& p) {
-    return 2 * p.ca * p.hq + 5 * p.cs * p.hq;   // x, dx, h_in, dgates
+    return p.ca * p.hq + (p.ca + 5 * p.cs) * (p.hq + 4);   // dx | x, h_in, dgates with rows hq + 4 apart (cell_wgrad_gemms)
 }
 __host__ __device__ inline int dec_act_floats(const sur_chunk_params& p, bool backward) {
     const int s = p.cs * p.hq, n = 4 * p.hq;
@@ -2710,21 +2714,29 @@ cell_wgrad_kernel(const sur_chunk_params p, const ChunkSpans spans, const float*
                   const float* __restrict__ h_all, const float* __restrict__ dg_all, int K, int B,
                   float* __restrict__ dxlat_t, int grads_in_lds, int row_base) {
     extern __shared__ __align__(16) float lds[];
-    const int s = p.cs * p.hq, nx = p.ca * p.hq, M = K * B;
+    const int s = p.cs * p.hq, nx = p.ca * p.hq, M = K * B, hq = p.hq, hs = hq + 4;
     StepLayout L{};
-    L.x = lds;
-    L.dx = L.x + nx;
-    L.h = L.dx + nx;
-    L.dgates = L.h + s;
-    float* wbase = L.dgates + 4 * s;
-    const float* w[SUR_ST_NPARAM];
-    stage_range<ST_NLSTM>(p, 0, wbase, w);
+    L.dx = lds;
+    L.x = L.dx + nx;
+    L.h = L.x + p.ca * hs;
+    L.dgates = L.h + p.cs * hs;
+    float* wbase = L.dgates + 4 * p.cs * hs;
+    // of the LSTM's weights only the four Wx_g are read here (dx); staged back to back.  (All twelve tensors were 15.6 KB: with
+    // the padded rows one workgroup too many for three per CU -- measured: 0.571 instead of 0.541 ms per step.)
+    const float* w[SUR_ST_NPARAM] = {};
+    int wx_floats = 0;
+    for (int gt = 0; gt < 4; ++gt) {
+        const int i = SUR_ST_WXI + 3 * gt;     // parameter order: Wx_g, b_g, Wh_g per gate
+        for (int j = threadIdx.x; j < p.size[i]; j += blockDim.x) wbase[wx_floats + j] = p.w[i][j];
+        w[i] = wbase + wx_floats;
+        wx_floats += p.size[i];
+    }
     int psize_lstm = 0;
     for (int i = 0; i < ST_NLSTM; ++i) psize_lstm += p.size[i];
     int psize = psize_lstm;
     for (int i = ST_NLSTM; i < SUR_ST_NPARAM; ++i) psize += p.size[i];
     float* row = p.partial + (size_t)(row_base + blockIdx.x) * psize;
-    float* gacc = grads_in_lds ? wbase + psize_lstm : row;
+    float* gacc = grads_in_lds ? wbase + wx_floats : row;
     float* g[SUR_ST_NPARAM];
     {
         int off = 0;
@@ -2743,10 +2755,27 @@ cell_wgrad_kernel(const sur_chunk_params p, const ChunkSpans spans, const float*
         const sur_chunk_span sp = spans.sp[si];
         const float* hin = (k - sp.k0 < sp.s) ? sp.lstates_t + ((size_t)(k - sp.k0) * B + b) * s
                                                : (k > sp.k0 ? h_all + ((size_t)(k - 1) * B + b) * s : sp.h0 + (size_t)b * sp.hc_bstride);
-        for (int i = threadIdx.x; i < nx; i += blockDim.x) L.x[i] = xlat_t[(size_t)m * nx + i];
-        for (int i = threadIdx.x; i < s; i += blockDim.x) L.h[i] = hin[i];
-        lds_load_v4(L.dgates, dg_all + (size_t)m * 4 * s, s);
-        cell_wgrad_gemms(p, L, w, g);
+        // rows land hs floats apart (float4 granules: hq is a multiple of 4)
+        const int q4 = hq >> 2;
+        auto padded = [&](int i4) { const int row = i4 / q4; return row * hs + 4 * (i4 - row * q4); };
+        {
+            const float4* xs = reinterpret_cast<const float4*>(xlat_t + (size_t)m * nx);
+            const float4* hsrc = reinterpret_cast<const float4*>(hin);
+            const float4* gs = reinterpret_cast<const float4*>(dg_all + (size_t)m * 4 * s);
+            for (int i = threadIdx.x; i < (nx >> 2); i += blockDim.x) *reinterpret_cast<float4*>(L.x + padded(i)) = xs[i];
+            for (int i = threadIdx.x; i < (s >> 2); i += blockDim.x) *reinterpret_cast<float4*>(L.h + padded(i)) = hsrc[i];
+            constexpr int U = 4;    // all of a thread's loads of a round in flight before the first store (lds_load_v4)
+            for (int i0 = threadIdx.x; i0 < s; i0 += U * TPB) {
+                float4 v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) v[u] = gs[i0 + u * TPB < s ? i0 + u * TPB : i0];
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (i0 + u * TPB < s) *reinterpret_cast<float4*>(L.dgates + padded(i0 + u * TPB)) = v[u];
+            }
+            __syncthreads();
+        }
+        cell_wgrad_gemms(p, L, w, g, hs);
         if (dxlat_t)
             for (int i = threadIdx.x; i < nx; i += blockDim.x) dxlat_t[(size_t)m * nx + i] = L.dx[i];
         __syncthreads();
@@ -3304,7 +3333,8 @@ static int chunks_backward_impl(void* stream, const sur_chunk_params* p, const C
     const int dec_gl = dec_base + sizeof(float) * psize_dec <= LDS_LIMIT ? 1 : 0;
     const size_t lds_dec = dec_base + (dec_gl ? sizeof(float) * psize_dec : 0);
     const size_t lds_cell = sizeof(float) * (cell_bwd_act_floats(*p) + psize_lstm);
-    const size_t wg_base = sizeof(float) * (cell_wgrad_act_floats(*p) + psize_lstm);
+    const size_t wg_base = sizeof(float) * (cell_wgrad_act_floats(*p) + p->size[SUR_ST_WXI] + p->size[SUR_ST_WXF] + p->size[SUR_ST_WXC] +
+                                            p->size[SUR_ST_WXO]);      // activations + the staged Wx_g
     const int wg_gl = wg_base + sizeof(float) * psize_lstm <= LDS_LIMIT ? 1 : 0;
     const size_t lds_wg = wg_base + (wg_gl ? sizeof(float) * psize_lstm : 0);
     if (int rc = set_lds(dec_bwd_kernel, lds_dec, "decoder backward")) return rc;
