@@ -70,6 +70,11 @@ typedef struct sur_chunk_params {
     int rows;
 } sur_chunk_params;
 
+/* 0 when the fused kernels implement this geometry (any pointer may be NULL), negative otherwise (sur_last_error()).
+ * The fused LayerNorm takes rows of 16, 32, 64, 128, 192 or 256 values: with the reference's strides (2, 2, 1) and the
+ * decoder's two transposed convolutions that is N in {64, 128, 256}.  Every launch checks the same and returns -4. */
+int sur_geometry_supported(const sur_encoder_params* state_enc, const sur_encoder_params* action_enc, const sur_chunk_params* chunk);
+
 /* Floats per sample of the forward intermediates sur_encoder_forward can save for sur_encoder_backward (0 = this
  * geometry has no saved-activation path).  With `saved` [M, sur_encoder_saved_floats] the backward kernel loads
  * the three blocks' intermediates instead of recomputing them (a third of its time); results are bit-identical. */

@@ -3021,6 +3021,36 @@ int sur_debug_stamps(long long* out128, int reset) {
 }
 #endif
 
+// The fused LayerNorm reduces a row with groups of 16, 32 or 64 lanes holding H / lanes elements each (act_ln_fwd): H is 16, 32
+// or a multiple of 64 up to 64 * LN_MAX_EPL.  Any other width would be normalised over a part of the row -- silently.
+static bool ln_width_ok(int h) { return h == 16 || h == 32 || (h >= 64 && h <= 64 * LN_MAX_EPL && (h & 63) == 0); }
+
+static int enc_geometry(const sur_encoder_params* p, const char* who) {
+    int h = p->n;
+    for (int b = 0; b < 3; ++b) {
+        if (p->stride[b] < 1 || h % p->stride[b]) return fail(-4, "%s: width %d is not a multiple of stride %d (block %d)", who, h, p->stride[b], b);
+        h /= p->stride[b];
+        if (!ln_width_ok(h))
+            return fail(-4, "%s: N = %d gives a LayerNorm row of %d in block %d; the fused kernels take 16, 32, 64, 128, 192, 256", who,
+                        p->n, h, b);
+    }
+    return 0;
+}
+
+static int chunk_geometry(const sur_chunk_params* p, const char* who) {
+    if (!ln_width_ok(2 * p->hq) || !ln_width_ok(4 * p->hq))
+        return fail(-4, "%s: N = %d gives LayerNorm rows of %d and %d in the decoder; the fused kernels take 16, 32, 64, 128, 192, 256", who,
+                    4 * p->hq, 2 * p->hq, 4 * p->hq);
+    return 0;
+}
+
+int sur_geometry_supported(const sur_encoder_params* state_enc, const sur_encoder_params* action_enc, const sur_chunk_params* chunk) {
+    if (state_enc) if (int rc = enc_geometry(state_enc, "state encoder")) return rc;
+    if (action_enc) if (int rc = enc_geometry(action_enc, "action encoder")) return rc;
+    if (chunk) if (int rc = chunk_geometry(chunk, "cell / decoder")) return rc;
+    return 0;
+}
+
 int sur_encoder_saved_floats(const sur_encoder_params* p) {
     if (!p) return 0;
     const int total = enc_saved_floats(*p);
@@ -3031,7 +3061,7 @@ int sur_encoder_forward(void* stream, const sur_encoder_params* p, const float* 
     if (!p || !x || !z || m <= 0) return fail(-1, "sur_encoder_forward: bad argument");
     if (saved && sur_encoder_saved_floats(p) == 0)
         return fail(-4, "sur_encoder_forward: this geometry has no saved-activation path (pass saved = NULL)");
-    if (p->n > 64 * LN_MAX_EPL * p->stride[0]) return fail(-4, "sur_encoder_forward: N = %d too wide for the fused LayerNorm", p->n);
+    if (int rc = enc_geometry(p, "sur_encoder_forward")) return rc;
     const int psize = psize_of<SUR_ENC_NPARAM>(p->size);
     const size_t lds = sizeof(float) * (enc_act_floats(*p, false) + psize);
     if (int rc = set_lds(enc_fwd_kernel, lds, "encoder forward")) return rc;
@@ -3043,6 +3073,7 @@ int sur_encoder_forward(void* stream, const sur_encoder_params* p, const float* 
 int sur_encoder_backward(void* stream, const sur_encoder_params* p, const float* x, const float* dz, int m, float* dx,
                          int row_base, int row_count, const float* saved) {
     if (!p || !x || !dz || m <= 0) return fail(-1, "sur_encoder_backward: bad argument");
+    if (int rc = enc_geometry(p, "sur_encoder_backward")) return rc;
     if (saved && sur_encoder_saved_floats(p) == 0)
         return fail(-4, "sur_encoder_backward: this geometry has no saved-activation path (pass saved = NULL)");
     if (!p->partial || row_count <= 0 || row_base < 0 || row_base + row_count > p->rows)
@@ -3075,7 +3106,7 @@ int sur_encoder_forward_multi(void* stream, int njobs, const sur_encoder_params*
             if (!p || !xs[j] || !zs[j] || !saveds[j] || ms[j] <= 0)
                 return fail(-1, "sur_encoder_forward_multi: job %d: bad argument (the `saved` buffer is required)", j);
             if (sur_encoder_saved_floats(p) == 0) return fail(-4, "sur_encoder_forward_multi: job %d: geometry not float4-granular", j);
-            if (p->n > 64 * LN_MAX_EPL * p->stride[0]) return fail(-4, "sur_encoder_forward_multi: N = %d too wide for the fused LayerNorm", p->n);
+            if (int rc = enc_geometry(p, "sur_encoder_forward_multi")) return rc;
             const EncBlockGeom gm = enc_block_geom(*p, blk);
             if (enc_narrow(*p)) {      // one wave per sample, a launch of its own
                 const int per_wg = TPB / 64, passes = (ms[j] + per_wg - 1) / per_wg;
@@ -3129,6 +3160,10 @@ int sur_encoder_backward_multi(void* stream, int njobs, const sur_encoder_params
                                const float* const* saveds, float* const* workspaces) {
     if (njobs < 1 || njobs > 3 || !ps || !xs || !dzs || !ms || !row_bases || !row_counts || !saveds)
         return fail(-1, "sur_encoder_backward_multi: bad argument (1 to 3 jobs)");
+    for (int j = 0; j < njobs; ++j) {
+        if (!ps[j]) return fail(-1, "sur_encoder_backward_multi: job %d: no parameters", j);
+        if (int rc = enc_geometry(ps[j], "sur_encoder_backward_multi")) return rc;
+    }
     bool split = workspaces != nullptr;
     for (int j = 0; j < njobs && split; ++j) split = saveds[j] && workspaces[j] && ps[j] && sur_encoder_saved_floats(ps[j]) > 0;
     if (split) {
@@ -3254,7 +3289,7 @@ int sur_chunk_forward(void* stream, const sur_chunk_params* p, const float* xlat
     if (!p || !xlat_t || !h0 || !c0 || !h_all || !c_all || !d_all || k <= 0 || b <= 0 || s < 1 ||
         !lstates_t || !states_t || hc_bstride < 0)
         return fail(-1, "sur_chunk_forward: bad argument (need K > 0, B > 0, S >= 1)");
-    if (4 * p->hq > 64 * LN_MAX_EPL) return fail(-4, "sur_chunk_forward: N = %d too wide for the fused LayerNorm", 4 * p->hq);
+    if (int rc = chunk_geometry(p, "sur_chunk_forward")) return rc;
     if (p->hq & 15) return fail(-4, "sur_chunk_forward: latent width N/4 = %d must be a multiple of 16", p->hq);
     if (saved && sur_chunk_saved_floats(p) == 0)
         return fail(-4, "sur_chunk_forward: hq = %d, ca = %d, cs = %d: no `saved` buffer for this geometry", p->hq, p->ca, p->cs);
@@ -3306,6 +3341,7 @@ static int chunks_backward_impl(void* stream, const sur_chunk_params* p, const C
                                 const float* h_all, const float* c_all, const float* dd_all, const float* dout_all,
                                 const float* dh_all, const float* dc_all, int k_total, int b, float* dxlat_t, float* dh0,
                                 float* dc0, int row_base, int row_count, const float* saved, float* workspace, const char* who) {
+    if (int rc = chunk_geometry(p, who)) return rc;
     if (!saved || !workspace) return fail(-1, "%s: needs the `saved` buffer the forward filled and a workspace", who);
     if (sur_chunk_saved_floats(p) == 0) return fail(-4, "%s: hq = %d, ca = %d, cs = %d: geometry not supported", who, p->hq, p->ca, p->cs);
     if (!p->partial || row_base < 0 || row_count < spans.n * b || p->rows < row_base + row_count)

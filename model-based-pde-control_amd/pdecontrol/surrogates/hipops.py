@@ -54,6 +54,7 @@ MAX_SPANS = 4
 _EP, _CP, _i = ctypes.POINTER(EncoderParams), ctypes.POINTER(ChunkParams), ctypes.c_int
 _AP = ctypes.POINTER(AdamParams)
 SYMBOLS = (
+    ("sur_geometry_supported", [_EP, _EP, _CP]),
     ("sur_encoder_saved_floats", [_EP]),
     ("sur_encoder_forward", [_fp, _EP, _fp, _i, _fp, _fp]),
     ("sur_encoder_backward", [_fp, _EP, _fp, _fp, _i, _fp, _i, _i, _fp]),
@@ -584,6 +585,31 @@ def fused_supported(surrogate):
         return len(getattr(surrogate.state_decoder.model, "layers", ())) == 4
     except Exception:
         return False
+
+
+_GEOMETRY = {}
+
+
+def geometry_unsupported(surrogate, n):
+    """None when the fused kernels implement grid width ``n`` for this (architecturally supported) surrogate, else the
+    library's reason.  The rule lives in the library (``sur_geometry_supported``: every LayerNorm row must be 16, 32 or a
+    multiple of 64 up to 256 values wide -- N in {64, 128, 256} with the reference's strides); every launch checks it too."""
+    strides = tuple(tuple(int(getattr(enc.model, name).conv3x3_l1.stride[0]) for name in enc.model.layers)
+                    for enc in (surrogate.state_encoder, surrogate.action_encoder))
+    key = (int(n), strides, int(surrogate.transition_model.ssize))
+    if key not in _GEOMETRY:
+        lib = load()
+        encs = []
+        for st in strides:
+            c = EncoderParams()
+            c.n = int(n)
+            c.stride[:] = st
+            encs.append(c)
+        ch = ChunkParams()
+        ch.hq = int(surrogate.transition_model.ssize)
+        rc = lib.sur_geometry_supported(ctypes.byref(encs[0]), ctypes.byref(encs[1]), ctypes.byref(ch))
+        _GEOMETRY[key] = None if rc == 0 else lib.sur_last_error().decode()
+    return _GEOMETRY[key]
 
 
 def packs_for(surrogate, n, batch):

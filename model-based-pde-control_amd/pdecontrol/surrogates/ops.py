@@ -3,8 +3,9 @@
 Every block of the surrogate goes through one of the functions below.  On CPU tensors they are
 plain torch (this is also the fp32 torch reference the HIP kernels are tested against).  On CUDA
 tensors the hand-written gfx950 kernels of libsurrogate_hip.so are THE path for the architecture they implement
-(``hipops.fused_supported``: the reference's KSAutoRegConvolutionalLSTM layout at any N): they are on by default and
-the library's absence raises at the first CUDA tensor.  Every call site asks ``use_fused_for(surrogate, tensor)``: an
+(``hipops.fused_supported``: the reference's KSAutoRegConvolutionalLSTM layout, at the grid widths whose LayerNorm rows
+the kernels reduce -- N = 64, 128, 256, ``hipops.geometry_unsupported``; any other width is announced once and runs on torch
+kernels like an uncovered architecture): they are on by default and the library's absence raises at the first CUDA tensor.  Every call site asks ``use_fused_for(surrogate, tensor)``: an
 architecture the kernels do not cover -- the reference also ships ``KSAutoRegFullyConnectedLSTM`` and trains it on the
 GPU as it is -- runs the plain PyTorch-ROCm path, announced ONCE per class through ``logging`` (never silently, and
 never the other way round: a covered architecture cannot end up on torch kernels without the explicit opt-out).  The
@@ -72,7 +73,15 @@ def use_fused_for(surrogate, tensor):
         return False
     from pdecontrol.surrogates import hipops
     if hipops.fused_supported(surrogate):
-        return use_fused(tensor)
+        if not use_fused(tensor):
+            return False
+        reason = hipops.geometry_unsupported(surrogate, tensor.shape[-1])
+        if reason is None:
+            return True
+        if reason not in _NOTIFIED:
+            _NOTIFIED.add(reason)
+            _LOG.warning("the fused HIP kernels do not implement this grid width (%s): it runs on plain PyTorch-ROCm kernels", reason)
+        return False
     name = type(surrogate).__name__ + "/" + type(getattr(surrogate, "transition_model", None)).__name__
     if name not in _NOTIFIED:
         _NOTIFIED.add(name)

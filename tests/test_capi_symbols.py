@@ -95,3 +95,11 @@ def test_surrogate_abi_rejects_bad_arguments_before_touching_the_device():
     enc.stride[0], enc.stride[1], enc.stride[2] = 2, 2, 1
     assert lib.sur_encoder_saved_floats(ctypes.byref(enc)) == 7 * (8 * 32 + 16 * 16 + 16 * 16)
     assert lib.sur_encoder_workspace_floats(ctypes.byref(enc), 10) == 10 * (8 * 32 + 16 * 16)
+    # grid widths: every LayerNorm row must be 16, 32 or a multiple of 64 up to 256 values wide
+    for n, ok in ((64, True), (128, True), (256, True), (32, False), (96, False), (192, False), (512, False)):
+        enc.n, chunk.hq = n, n // 4
+        rc = lib.sur_geometry_supported(ctypes.byref(enc), ctypes.byref(enc), ctypes.byref(chunk))
+        assert (rc == 0) == ok, (n, rc, lib.sur_last_error())
+        if not ok:
+            assert rc == -4 and b"LayerNorm" in lib.sur_last_error()
+            assert lib.sur_encoder_forward(null, ctypes.byref(enc), ctypes.c_void_p(16), 4, ctypes.c_void_p(16), null) == -4

@@ -208,10 +208,12 @@ def test_ensemble_parallel_step_equals_member_by_member(dev):
         ops.reset_fused()
 
 
-@pytest.mark.parametrize("N", [64, 256])
+@pytest.mark.parametrize("N", [64, 128, 256])
 def test_encoder_saved_activations_backward_matches_recompute(dev, N, monkeypatch):
     """Encoder backward fed with the forward's saved intermediates (one residual block per launch) against the
-    whole-encoder kernel that recomputes them: same forward, gradients equal up to summation grouping."""
+    whole-encoder kernel that recomputes them: same forward, gradients equal up to summation grouping.  For the 1-2-4-4
+    action encoder this is also the one-wave-per-sample VALU blocks (csrc/sur_kernels.hip ``nr_*``: the per-block launches
+    route it there) against the MFMA gather-GEMM blocks of the whole-encoder kernel, at three widths."""
     from pdecontrol.surrogates import hipops, ops
     g = torch.Generator().manual_seed(3)
     states = (torch.rand(8, 20, 1, N, generator=g) * 2 - 1).to(dev)
@@ -363,6 +365,76 @@ def test_fused_tbptt_other_chunkings(dev, T):
     check_grads(f"fused vs plain torch kernels, same device (T={T})",
                 {k: v.detach().cpu().numpy() for k, v in gf.items()}, lambda k: gt[k].detach().cpu().numpy(),
                 tol=2e-3)   # B = 6 random sequences, both sides fp32 on the GPU: observed <= 3.5e-4 (decoder bias behind a LayerNorm)
+
+
+def test_fused_training_step_at_a_third_grid_width(dev):
+    """N = 128 (between the two benchmark sizes): the shape-specialised primitives -- narrow action-encoder blocks, parity-
+    sorted transposed convolutions, single-channel layers as one tile -- at widths 64 / 32 / 128.  Fused step against the
+    plain torch path on the same GPU."""
+    from pdecontrol.surrogates import ops
+    N = 128
+    g = torch.Generator().manual_seed(N)
+    states = (torch.rand(5, 20, 1, N, generator=g) * 2 - 1).to(dev)
+    actions = (torch.rand(5, 20, 1, N, generator=g) * 2 - 1).to(dev)
+    res = {}
+    try:
+        for fused in (False, True):
+            ops.enable_fused(fused)
+            m = _build(dev, N=N)
+            if fused:
+                assert ops.use_fused_for(m.surrogate, states), "the fused path must take this geometry"
+            out = m.training_step((states, actions), 0)
+            out["loss"].backward()
+            torch.cuda.synchronize(dev)
+            res[fused] = (out, _grads(m))
+    finally:
+        ops.reset_fused()
+    (ot, gt), (of, gf) = res[False], res[True]
+    np.testing.assert_allclose(float(of["loss"].detach()), float(ot["loss"].detach()), rtol=1e-5)
+    _close(of["outputs"], ot["outputs"], rtol=1e-3, atol_scale=1e-4, msg="outputs")
+    assert gf.keys() == gt.keys()
+    from conftest import check_grads
+    check_grads(f"fused vs plain torch kernels, same device (N={N})",
+                {k: v.detach().cpu().numpy() for k, v in gf.items()}, lambda k: gt[k].detach().cpu().numpy(), tol=2e-3)
+
+
+@pytest.mark.parametrize("N", [96, 192, 512])
+def test_grid_widths_the_fused_layernorm_cannot_reduce_are_refused(dev, N, caplog):
+    """The fused LayerNorm reduces rows of 16, 32 or k * 64 <= 256 values: N = 96 / 192 give rows of 24 / 48 / 96, N = 512 rows of
+    512.  (Before the check N = 96 normalised 64 of 96 values: loss off by 5e-4, silently.)  The library refuses the geometry
+    -- every launch returns -4 -- and the module runs such a surrogate on the torch kernels with ONE logged notice, like an
+    architecture the kernels do not cover: same loss as with the fused path switched off."""
+    import ctypes
+    import logging
+    from pdecontrol.surrogates import hipops, ops
+    g = torch.Generator().manual_seed(N)
+    states = (torch.rand(3, 12, 1, N, generator=g) * 2 - 1).to(dev)
+    actions = (torch.rand(3, 12, 1, N, generator=g) * 2 - 1).to(dev)
+    losses = {}
+    try:
+        for fused in (False, True):
+            ops.enable_fused(fused)
+            m = _build(dev, N=N)
+            if fused:
+                with caplog.at_level(logging.WARNING, logger="pdecontrol.surrogates"):
+                    assert not ops.use_fused_for(m.surrogate, states)
+                    assert not ops.use_fused_for(m.surrogate, states)
+                reason = hipops.geometry_unsupported(m.surrogate, N)
+                assert reason and "LayerNorm" in reason
+                assert sum("grid width" in r.getMessage() for r in caplog.records) <= 1   # once per reason (module-level memory)
+                packs = hipops.FusedPacks(m.surrogate, N, 3)       # a caller that goes to the C ABI anyway is turned away there
+                x = torch.zeros(3, 1, N, device=dev)
+                z = torch.zeros(3, packs.state_enc.c.c[3], N // 4, device=dev)
+                rc = hipops.load().sur_encoder_forward(None, ctypes.byref(packs.state_enc.c), x.data_ptr(), 3, z.data_ptr(), None)
+                msg = hipops.load().sur_last_error()
+                assert rc == -4 and (b"LayerNorm" in msg or (N == 512 and b"LDS" in msg)), msg   # 512: the encoder's rows fit, its LDS does not
+            out = m.training_step((states, actions), 0)
+            out["loss"].backward()
+            torch.cuda.synchronize(dev)
+            losses[fused] = float(out["loss"].detach())
+    finally:
+        ops.reset_fused()
+    assert losses[True] == losses[False]
 
 
 def test_pack_adam_matches_torch_adam_and_lightning_closure_order(dev):
