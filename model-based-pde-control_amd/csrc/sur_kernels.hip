@@ -131,6 +131,7 @@ __device__ __forceinline__ int wrapi(int j, int n) { return j < 0 ? j + n : (j >
 // B[k=l>>4][l&15], result reg i of lane l = C[4*(l>>4)+i][l&15].
 // ---------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) float lds_f;   // a float the compiler KNOWS to be in LDS (ds_read / ds_write, 32-bit address)
 
 // Flavour 1 -- reduction over (segment, tap, channel):
 //   C[m][n] = sum_seg sum_{t<T} sum_{c<cin} A_seg[m*a_sm + c*a_sc + t] * B_seg[c*b_sc + col(seg, t, n)]
@@ -2171,8 +2172,11 @@ __device__ __forceinline__ void cell_chain_forward(const sur_chunk_params& p, fl
                                                    float* __restrict__ h_all, float* __restrict__ c_all,
                                                    float* __restrict__ saved) {
     const int hq = p.hq, ca = p.ca, s = 16 * hq, nx = ca * hq;
-    float* xb[2] = {lds, lds + nx};
-    float* hb[2] = {lds + 2 * nx, lds + 2 * nx + s};
+    // LDS-typed pointers: through a generic `float*` picked from an array by (k & 1) the operand reads of the time loop were
+    // flat_load_dword -- 64-bit address arithmetic per read and, because a flat access may be a global one, an
+    // s_waitcnt vmcnt(0) in front of every MFMA group: each step waited for its own prefetch and the previous step's stores
+    lds_f* const xbase = (lds_f*)lds;
+    lds_f* const hbase = xbase + 2 * nx;
     const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, tset = NSETS > 1 ? tid >> 8 : 0;
     const int r = lane & 15, q = lane >> 4;
     const int n = 16 * tset + r, ch = 4 * wave + q, idx = ch * hq + n;
@@ -2192,8 +2196,8 @@ __device__ __forceinline__ void cell_chain_forward(const sur_chunk_params& p, fl
     }
     const float bi = p.w[SUR_ST_BXI][ch], bf = p.w[SUR_ST_BXF][ch], bc = p.w[SUR_ST_BXC][ch], bo = p.w[SUR_ST_BXO][ch];
     float c_reg = c0[(size_t)b * hc_bstride + idx];
-    hb[0][idx] = S > 0 ? lstates_t[(size_t)b * s + idx] : h0[(size_t)b * hc_bstride + idx];
-    if (tid < nx) xb[0][tid] = xlat_t[(size_t)b * nx + tid];
+    hbase[idx] = S > 0 ? lstates_t[(size_t)b * s + idx] : h0[(size_t)b * hc_bstride + idx];
+    if (tid < nx) xbase[tid] = xlat_t[(size_t)b * nx + tid];
     const size_t save_stride = step_saved_floats(p);
     int colx[3];
 #pragma unroll
@@ -2205,8 +2209,8 @@ __device__ __forceinline__ void cell_chain_forward(const sur_chunk_params& p, fl
         float xnext = 0.0f, hforced = 0.0f;
         if (nxt && tid < nx) xnext = xlat_t[(kb + B) * nx + tid];
         if (next_forced) hforced = lstates_t[(kb + B) * s + idx];
-        const float* xc = xb[k & 1];
-        const float* hc = hb[k & 1];
+        const lds_f* xc = xbase + (k & 1) * nx;
+        const lds_f* hc = hbase + (k & 1) * s;
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int tap = 0; tap < 3; ++tap) {
@@ -2237,8 +2241,8 @@ __device__ __forceinline__ void cell_chain_forward(const sur_chunk_params& p, fl
             dst[5 * s] = hn;
         }
         if (nxt) {
-            hb[(k + 1) & 1][idx] = next_forced ? hforced : hn;   // teacher forcing replaces H
-            if (tid < nx) xb[(k + 1) & 1][tid] = xnext;
+            hbase[((k + 1) & 1) * s + idx] = next_forced ? hforced : hn;   // teacher forcing replaces H
+            if (tid < nx) xbase[((k + 1) & 1) * nx + tid] = xnext;
         }
         __syncthreads();
     }
