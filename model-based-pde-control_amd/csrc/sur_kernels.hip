@@ -2510,8 +2510,8 @@ __device__ __forceinline__ void cell_chain_backward(const sur_chunk_params& p, f
     const float* __restrict__ c0 = sp.c0;
     const int hc_bstride = sp.hc_bstride;
     float* __restrict__ dlstates_t = sp.dlstates_t;
-    float* dgates = lds;              // [4][s]
-    float* part = lds + 4 * s;        // [4][s]
+    lds_f* const dgates = (lds_f*)lds;    // [4][s]   LDS-typed: as generic pointers these were flat accesses, whose
+    lds_f* const part = dgates + 4 * s;   // [4][s]   s_waitcnt vmcnt(0) drained the two-steps-ahead prefetch every step
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
     const int gt = wid / NSETS, n0 = 16 * (wid % NSETS);
@@ -2578,11 +2578,11 @@ __device__ __forceinline__ void cell_chain_backward(const sur_chunk_params& p, f
         __syncthreads();
         // ---- B: dh_{k-1} partial of gate gt, column tile n0: sum_{o, tap} Wh_gt[o][ci][tap] * dG_gt[o][j - tap + 1] ----
         {
-            const float* bsrc = dgates + gt * s;
+            const lds_f* bsrc = dgates + gt * s;
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int tap = 0; tap < 3; ++tap) {
-                const float* bp = bsrc + colj[tap];
+                const lds_f* bp = bsrc + colj[tap];
 #pragma unroll
                 for (int blk = 0; blk < 4; blk += 2) {
                     const float b0 = bp[(4 * blk + q) * hq], b1 = bp[(4 * blk + 4 + q) * hq];
@@ -2590,7 +2590,7 @@ __device__ __forceinline__ void cell_chain_backward(const sur_chunk_params& p, f
                     acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tap][blk + 1], b1, acc1, 0, 0, 0);
                 }
             }
-            float* dst = part + gt * s + n0 + r;
+            lds_f* dst = part + gt * s + n0 + r;
 #pragma unroll
             for (int e = 0; e < 4; ++e) dst[(4 * q + e) * hq] = acc0[e] + acc1[e];
         }
