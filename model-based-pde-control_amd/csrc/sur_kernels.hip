@@ -23,6 +23,7 @@
 // samples in LDS, added to the workgroup's own row of a partial buffer (no atomics, so results are deterministic)
 // and reduced over rows by a flush kernel.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include <cstdarg>
 #include <cstdio>
@@ -343,9 +344,12 @@ __device__ void conv_bwd_data(const float* dout, int cout, int hin, const float*
 
 // gW[o][ci][k] += sum_p dout[o][p] * in[ci][(p*stride + k - pad) mod hin];  gb[o] += sum_p dout[o][p]
 // `scratch` (LDS, scratch_floats floats, not aliasing any operand): lets the single-output-channel case run as an MFMA tile.
-template <int K>
+// GP: the accumulators' pointer type -- `lds_f*` when the kernel knows them to be in LDS (plain ds_read / ds_write), `float*` when
+// they may be the partial row in global memory (a generic pointer: flat_load / flat_store, whose s_waitcnt also drains every
+// outstanding global load and store of the wave).
+template <int K, class GP>
 __device__ void conv_bwd_weight(const float* dout, int cout, const float* in, int cin, int hin, int stride, int pad,
-                                float* gW, float* gb, WaveSet ws = WaveSet{0, 1 << 20}, bool sync = true, float* scratch = nullptr,
+                                GP gW, GP gb, WaveSet ws = WaveSet{0, 1 << 20}, bool sync = true, float* scratch = nullptr,
                                 int scratch_floats = 0) {
     const int hout = hin / stride, ncols = cin * K;
     if (cout == 1 && stride == 1 && K <= 16 && cin < 16 && (cin + 1) * K <= 64 && scratch_floats >= 64 && (hin & 3) == 0) {
@@ -489,7 +493,8 @@ __device__ void deconv_bwd_data(const float* dout, int cout, int hin, const floa
                     });
 }
 
-__device__ void deconv_bwd_weight(const float* dout, int cout, const float* in, int cin, int hin, float* gW, float* gb,
+template <class GP>
+__device__ void deconv_bwd_weight(const float* dout, int cout, const float* in, int cin, int hin, GP gW, GP gb,
                                   WaveSet ws = WaveSet{0, 1 << 20}, bool sync = true) {
     const int hout = 2 * hin, ncols = cout * 3;
     {
@@ -572,8 +577,9 @@ __device__ void act_ln_fwd(const float* pre, int C, int H, const float* gamma, c
 }
 
 // backward of act_ln_fwd: dpre from dout; accumulates ggamma / gbeta.  xhat_scratch: [C][H] work space.
+template <class GP>
 __device__ void act_ln_bwd(const float* dout, const float* pre, int C, int H, const float* gamma, bool silu,
-                           float* dpre, float* xhat_scratch, float* ggamma, float* gbeta) {
+                           float* dpre, float* xhat_scratch, GP ggamma, GP gbeta) {
     const int lpc = H < 64 ? H : 64, gpw = 64 / lpc, epl = H / lpc;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int grp = lane / lpc, gl = lane - grp * lpc;
@@ -763,7 +769,8 @@ __device__ void rb_forward(const RBBuf& b, const float* const* w) {
 // dout [cout][hout] -> din [cin][hin]; g1, g2, g3, xh: scratch of cout*hout floats each
 // need_din = false (the encoder's first block: its input is data): the two data-gradient GEMMs onto the block input are
 // skipped -- with cin = 1 they fill one row of every 16-row MFMA tile and were the longest phase of that block.
-__device__ void rb_backward(const RBBuf& b, const float* const* w, float* const* g, const float* dout, float* din,
+template <class GP>
+__device__ void rb_backward(const RBBuf& b, const float* const* w, const GP* g, const float* dout, float* din,
                             float* g1, float* g2, float* g3, float* xh, int sb = -1, bool need_din = true) {
 #ifdef SUR_STAMP
 #define RB_STAMP(i) do { if (sb >= 0) STAMP(sb + (i)); } while (0)
@@ -774,26 +781,26 @@ __device__ void rb_backward(const RBBuf& b, const float* const* w, float* const*
     RB_STAMP(0);
     // skip path
     if (need_din) {
-        conv_bwd_weight<1>(g1, b.cout, b.in, b.cin, b.hin, b.stride, 0, g[SUR_RB_SKIP], nullptr, lower_half(), false);
+        conv_bwd_weight<1>(g1, b.cout, b.in, b.cin, b.hin, b.stride, 0, g[SUR_RB_SKIP], GP(nullptr), lower_half(), false);
         conv_bwd_data<1>(g1, b.cout, b.hin, w[SUR_RB_SKIP], b.cin, b.stride, 0, din, false, upper_half(), true);
     } else {
-        conv_bwd_weight<1>(g1, b.cout, b.in, b.cin, b.hin, b.stride, 0, g[SUR_RB_SKIP], nullptr, all_waves(), false);
+        conv_bwd_weight<1>(g1, b.cout, b.in, b.cin, b.hin, b.stride, 0, g[SUR_RB_SKIP], GP(nullptr), all_waves(), false);
         // no barrier: the next phase reads g1 / a2pre and writes g2, xh and the LayerNorm accumulators only
     }
     RB_STAMP(1);
     // residual path
     act_ln_bwd(g1, b.a2pre, b.cout, b.hout, w[SUR_RB_LN2_W], true, g2, xh, g[SUR_RB_LN2_W], g[SUR_RB_LN2_B]);
     RB_STAMP(2);
-    conv_bwd_weight<3>(g2, b.cout, b.a1, b.cout, b.hout, 1, 1, g[SUR_RB_CONV2], nullptr, lower_half(), false);
+    conv_bwd_weight<3>(g2, b.cout, b.a1, b.cout, b.hout, 1, 1, g[SUR_RB_CONV2], GP(nullptr), lower_half(), false);
     conv_bwd_data<3>(g2, b.cout, b.hout, w[SUR_RB_CONV2], b.cout, 1, 1, g3, false, upper_half(), true);
     RB_STAMP(3);
     act_ln_bwd(g3, b.a1pre, b.cout, b.hout, w[SUR_RB_LN1_W], true, g1, xh, g[SUR_RB_LN1_W], g[SUR_RB_LN1_B]);
     RB_STAMP(4);
     if (need_din) {
-        conv_bwd_weight<3>(g1, b.cout, b.in, b.cin, b.hin, b.stride, 1, g[SUR_RB_CONV1], nullptr, lower_half(), false);
+        conv_bwd_weight<3>(g1, b.cout, b.in, b.cin, b.hin, b.stride, 1, g[SUR_RB_CONV1], GP(nullptr), lower_half(), false);
         conv_bwd_data<3>(g1, b.cout, b.hin, w[SUR_RB_CONV1], b.cin, b.stride, 1, din, true, upper_half(), true);
     } else {
-        conv_bwd_weight<3>(g1, b.cout, b.in, b.cin, b.hin, b.stride, 1, g[SUR_RB_CONV1], nullptr, all_waves(), true);
+        conv_bwd_weight<3>(g1, b.cout, b.in, b.cin, b.hin, b.stride, 1, g[SUR_RB_CONV1], GP(nullptr), all_waves(), true);
     }
     RB_STAMP(5);
 #undef RB_STAMP
@@ -1992,8 +1999,8 @@ __device__ void decoder_forward(const sur_chunk_params& p, const StepLayout& L, 
 // buffer once the middle norm's backward has read p1 (`late_p0`), h into a0's buffer once the second transposed
 // convolution's weight gradient has read a0 (`late_h`).  Each is stored right after a barrier that retires the old
 // contents and at least one barrier before its first reader.
-template <typename StoreP0, typename StoreH>
-__device__ void decoder_backward(const sur_chunk_params& p, const StepLayout& L, const float* const* w, float* const* g,
+template <class GP, typename StoreP0, typename StoreH>
+__device__ void decoder_backward(const sur_chunk_params& p, const StepLayout& L, const float* const* w, const GP* g,
                                  StoreP0 late_p0, StoreH late_h) {
     const int n = L.n;
     // single-channel gradients fill the first n floats of gA: the rest of the buffer is the weight gradients' scratch
@@ -2048,7 +2055,8 @@ __device__ void cell_dh_gemm(const sur_chunk_params& p, const StepLayout& L, con
 // `hs`: floats between consecutive rows of L.x, L.h and L.dgates (>= hq).  With hs = hq = 64 the sixteen tile rows a GEMM operand
 // is gathered from start in the same LDS bank (SQ_LDS_BANK_CONFLICT was 79 % of the LDS-active cycles of this kernel);
 // hs = hq + 4 staggers them by four banks and keeps rows 16-byte aligned.
-__device__ void cell_wgrad_gemms(const sur_chunk_params& p, const StepLayout& L, const float* const* w, float* const* g, int hs) {
+template <class GP>
+__device__ void cell_wgrad_gemms(const sur_chunk_params& p, const StepLayout& L, const float* const* w, const GP* g, int hs) {
     const int s = p.cs * hs, nwg = blockDim.x >> 6, cs = p.cs, ca = p.ca, hq = p.hq;
     const int gate_stride = (int)(w[SUR_ST_WXF] - w[SUR_ST_WXI]);     // between the gates' Wx as staged (cell_wgrad_kernel: back to back)
     const int ggate_stride = (int)(g[SUR_ST_WXF] - g[SUR_ST_WXI]);    // between the gates' accumulators (parameter order)
@@ -2068,7 +2076,7 @@ __device__ void cell_wgrad_gemms(const sur_chunk_params& p, const StepLayout& L,
     }
     struct St { const float* row; int off; };
     {   // weight gradients, all gates in one GEMM each: rows m = (gate, o)
-        float* gx = g[SUR_ST_WXI];
+        const GP gx = g[SUR_ST_WXI];
         const float* xin = L.x;
         const int ncols = ca * 3;
         gemm_pos(w_gw, false, 4 * cs, ncols, hq, L.dgates, hs,
@@ -2080,7 +2088,7 @@ __device__ void cell_wgrad_gemms(const sur_chunk_params& p, const StepLayout& L,
                          gx[gt * ggate_stride + o * ncols + n] += v;
                      }
                  });
-        float* gh = g[SUR_ST_WHI];
+        const GP gh = g[SUR_ST_WHI];
         const float* hin_ = L.h;
         const int ncols_h = cs * 3;
         gemm_pos(w_gw, false, 4 * cs, ncols_h, hq, L.dgates, hs,
@@ -2093,7 +2101,7 @@ __device__ void cell_wgrad_gemms(const sur_chunk_params& p, const StepLayout& L,
                      }
                  });
         // bias gradients: one 16-lane group per (gate, channel) row of dG
-        float* gbx = g[SUR_ST_BXI];
+        const GP gbx = g[SUR_ST_BXI];
         const int group = threadIdx.x >> 4, gl = threadIdx.x & 15, ngroups = blockDim.x >> 4;
         for (int r0 = 0; r0 < 4 * cs; r0 += ngroups) {
             const int r = r0 + group;
@@ -2392,9 +2400,12 @@ dgrad_scan_kernel(const float* __restrict__ dd_all, const float* __restrict__ do
 #endif
 constexpr int DEC_LATE_P0 = 2;   // float4 registers per thread for the late p0: cs * 2 hq <= 2 * 4 * TPB
 constexpr int DEC_LATE_H = 1;    //                                  ... for the late h:  cs * hq <= 4 * TPB
+// GL: the gradient accumulators are in LDS (behind the staged weights) -- known at compile time, so that they are LDS-typed
+// pointers (see conv_bwd_weight); GL = false accumulates straight into the workgroup's partial row.
+template <bool GL>
 __global__ void __launch_bounds__(TPB, DEC_BWD_OCC)
 dec_bwd_kernel(const sur_chunk_params p, const float* __restrict__ saved, const float* __restrict__ ga_all, int M,
-               float* __restrict__ dh_dec, int grads_in_lds, int row_base) {
+               float* __restrict__ dh_dec, int row_base) {
     extern __shared__ __align__(16) float lds[];
     const int s = p.cs * p.hq, n = 4 * p.hq, mx = step_max_act(p);
     const int a0f = p.cs * 2 * p.hq, a1f = p.c_mid * n;
@@ -2421,15 +2432,18 @@ dec_bwd_kernel(const sur_chunk_params p, const float* __restrict__ saved, const 
     for (int i = ST_NLSTM; i < SUR_ST_NPARAM; ++i) psize_dec += p.size[i];
     const int psize = off_dec + psize_dec;
     float* row = p.partial + (size_t)(row_base + blockIdx.x) * psize + off_dec;
-    float* gacc = grads_in_lds ? wbase + psize_dec : row;
-    float* g[SUR_ST_NPARAM];
+    typedef typename std::conditional<GL, lds_f*, float*>::type GP;
+    GP gacc;
+    if constexpr (GL) gacc = (lds_f*)(wbase + psize_dec);
+    else gacc = row;
+    GP g[SUR_ST_NPARAM];
     {
         int off = 0;
         for (int i = ST_NLSTM; i < SUR_ST_NPARAM; ++i) {
             g[i] = gacc + off;
             off += p.size[i];
         }
-        if (grads_in_lds)
+        if (GL)
             for (int j = threadIdx.x; j < psize_dec; j += blockDim.x) gacc[j] = 0.0f;
     }
     __syncthreads();
@@ -2473,7 +2487,7 @@ dec_bwd_kernel(const sur_chunk_params p, const float* __restrict__ saved, const 
         for (int i = threadIdx.x; i < s; i += blockDim.x) dh_dec[(size_t)m * s + i] = L.dh[i];
         __syncthreads();
     }
-    if (grads_in_lds) add_to_row(row, gacc, psize_dec);
+    if constexpr (GL) add_to_row(row, (const float*)gacc, psize_dec);
 }
 
 // BPTT through the cell chain of one sample: consumes dh_dec (decoder) and the upstream dh / dc gradients, emits the
@@ -2713,10 +2727,11 @@ cell_bwd_kernel(const sur_chunk_params p, const ChunkSpans spans, const float* _
 
 // Everything of the cell backward that is not recurrent, for all (step, sample) pairs in parallel: the gradient wrt
 // the latent action and the LSTM weight / bias gradients (into this workgroup's partial row).
+template <bool GL>      // as dec_bwd_kernel
 __global__ void __launch_bounds__(TPB, PAR_OCC)
 cell_wgrad_kernel(const sur_chunk_params p, const ChunkSpans spans, const float* __restrict__ xlat_t,
                   const float* __restrict__ h_all, const float* __restrict__ dg_all, int K, int B,
-                  float* __restrict__ dxlat_t, int grads_in_lds, int row_base) {
+                  float* __restrict__ dxlat_t, int row_base) {
     extern __shared__ __align__(16) float lds[];
     const int s = p.cs * p.hq, nx = p.ca * p.hq, M = K * B, hq = p.hq, hs = hq + 4;
     StepLayout L{};
@@ -2740,15 +2755,18 @@ cell_wgrad_kernel(const sur_chunk_params p, const ChunkSpans spans, const float*
     int psize = psize_lstm;
     for (int i = ST_NLSTM; i < SUR_ST_NPARAM; ++i) psize += p.size[i];
     float* row = p.partial + (size_t)(row_base + blockIdx.x) * psize;
-    float* gacc = grads_in_lds ? wbase + wx_floats : row;
-    float* g[SUR_ST_NPARAM];
+    typedef typename std::conditional<GL, lds_f*, float*>::type GP;
+    GP gacc;
+    if constexpr (GL) gacc = (lds_f*)(wbase + wx_floats);
+    else gacc = row;
+    GP g[SUR_ST_NPARAM];
     {
         int off = 0;
         for (int i = 0; i < ST_NLSTM; ++i) {
             g[i] = gacc + off;
             off += p.size[i];
         }
-        if (grads_in_lds)
+        if (GL)
             for (int j = threadIdx.x; j < psize_lstm; j += blockDim.x) gacc[j] = 0.0f;
     }
     __syncthreads();
@@ -2784,7 +2802,7 @@ cell_wgrad_kernel(const sur_chunk_params p, const ChunkSpans spans, const float*
             for (int i = threadIdx.x; i < nx; i += blockDim.x) dxlat_t[(size_t)m * nx + i] = L.dx[i];
         __syncthreads();
     }
-    if (grads_in_lds) add_to_row(row, gacc, psize_lstm);
+    if constexpr (GL) add_to_row(row, (const float*)gacc, psize_lstm);
 }
 
 // g[i][j] += sum_r partial[r][off_i + j]; the partial rows are re-zeroed.  With an Adam descriptor the reduced gradient is
@@ -3377,12 +3395,14 @@ static int chunks_backward_impl(void* stream, const sur_chunk_params* p, const C
                                             p->size[SUR_ST_WXO]);      // activations + the staged Wx_g
     const int wg_gl = wg_base + sizeof(float) * psize_lstm <= LDS_LIMIT ? 1 : 0;
     const size_t lds_wg = wg_base + (wg_gl ? sizeof(float) * psize_lstm : 0);
-    if (int rc = set_lds(dec_bwd_kernel, lds_dec, "decoder backward")) return rc;
-    if (int rc = set_lds(cell_wgrad_kernel, lds_wg, "cell weight gradients")) return rc;
+    if (int rc = dec_gl ? set_lds(dec_bwd_kernel<true>, lds_dec, "decoder backward") : set_lds(dec_bwd_kernel<false>, lds_dec, "decoder backward"))
+        return rc;
+    if (int rc = wg_gl ? set_lds(cell_wgrad_kernel<true>, lds_wg, "cell weight gradients") : set_lds(cell_wgrad_kernel<false>, lds_wg, "cell weight gradients"))
+        return rc;
     const int grid = m < row_count ? m : row_count;
     if (int rc = launch_checked([&] {
-            hipLaunchKernelGGL(dec_bwd_kernel, dim3(grid), dim3(TPB), lds_dec, (hipStream_t)stream, *p, saved, ga, m, dh_dec, dec_gl,
-                               row_base);
+            if (dec_gl) hipLaunchKernelGGL(dec_bwd_kernel<true>, dim3(grid), dim3(TPB), lds_dec, (hipStream_t)stream, *p, saved, ga, m, dh_dec, row_base);
+            else hipLaunchKernelGGL(dec_bwd_kernel<false>, dim3(grid), dim3(TPB), lds_dec, (hipStream_t)stream, *p, saved, ga, m, dh_dec, row_base);
         }, "dec_bwd")) return rc;
     const int chain_threads = cell_chain_threads(*p);
     auto launch_cell_bwd = [&](auto kernel) -> int {
@@ -3397,8 +3417,8 @@ static int chunks_backward_impl(void* stream, const sur_chunk_params* p, const C
                                                                   : launch_cell_bwd(cell_bwd_kernel<4 * TPB>)))
         return rc;
     return launch_checked([&] {
-        hipLaunchKernelGGL(cell_wgrad_kernel, dim3(grid), dim3(TPB), lds_wg, (hipStream_t)stream, *p, spans, xlat_t, h_all, dg_all,
-                           k_total, b, dxlat_t, wg_gl, row_base);
+        if (wg_gl) hipLaunchKernelGGL(cell_wgrad_kernel<true>, dim3(grid), dim3(TPB), lds_wg, (hipStream_t)stream, *p, spans, xlat_t, h_all, dg_all, k_total, b, dxlat_t, row_base);
+        else hipLaunchKernelGGL(cell_wgrad_kernel<false>, dim3(grid), dim3(TPB), lds_wg, (hipStream_t)stream, *p, spans, xlat_t, h_all, dg_all, k_total, b, dxlat_t, row_base);
     }, "cell_wgrad");
 }
 
