@@ -1454,6 +1454,7 @@ struct EncBlockJob {
     int m, row_base, wg_begin, wg_count, grads_in_lds;
 };
 
+template <bool GL>     // GL: this job's gradient accumulators are in LDS (j.grads_in_lds), as LDS-typed pointers (conv_bwd_weight)
 __device__ __forceinline__ void enc_block_bwd_body(const EncBlockJob& j, int blk, int wg, float* lds) {
     const sur_encoder_params& p = j.p;
     const EncBlockGeom gm = enc_block_geom(p, blk);
@@ -1476,8 +1477,21 @@ __device__ __forceinline__ void enc_block_bwd_body(const EncBlockJob& j, int blk
     stage_weights<SUR_RB_NPARAM>(p.w + SUR_RB_NPARAM * blk, p.size + SUR_RB_NPARAM * blk, cur, v);
     const int psize = psize_of<SUR_ENC_NPARAM>(p.size);
     float* row = p.partial + (size_t)(j.row_base + wg) * psize + gm.param_off;
-    float* gacc = j.grads_in_lds ? cur + gm.psize_blk : row;
-    setup_grads<SUR_RB_NPARAM>(p.size + SUR_RB_NPARAM * blk, gacc, j.grads_in_lds != 0, v);
+    typedef typename std::conditional<GL, lds_f*, float*>::type GP;
+    GP gacc, g[SUR_RB_NPARAM];
+    if constexpr (GL) gacc = (lds_f*)(cur + gm.psize_blk);
+    else gacc = row;
+    {
+        int off = 0;
+#pragma unroll
+        for (int i = 0; i < SUR_RB_NPARAM; ++i) {
+            g[i] = gacc + off;
+            off += p.size[SUR_RB_NPARAM * blk + i];
+        }
+        if (GL)
+            for (int t = threadIdx.x; t < off; t += blockDim.x) gacc[t] = 0.0f;
+        __syncthreads();
+    }
     STAMP(sbase + 1);
     const int nsv = enc_saved_floats(p), nws = enc_ws_floats(p);
     const int h1 = p.n / p.stride[0];
@@ -1495,7 +1509,7 @@ __device__ __forceinline__ void enc_block_bwd_body(const EncBlockJob& j, int blk
         lds_load_v4(rb.s, rec + gm.saved_off + 5 * a, a >> 2);
         lds_load_v4(dout, dsrc, a >> 2);
         STAMP(sbase + 2);
-        rb_backward(rb, v.w, v.g, dout, din, g1, g2, g3, xh, sbase + 3, blk > 0);
+        rb_backward(rb, v.w, g, dout, din, g1, g2, g3, xh, sbase + 3, blk > 0);
         if (blk > 0) {
             float* dst = j.ws + (size_t)m * nws + (blk == 2 ? ws_in_off : 0);
             for (int i = threadIdx.x; i < nin; i += blockDim.x) dst[i] = din[i];
@@ -1503,7 +1517,7 @@ __device__ __forceinline__ void enc_block_bwd_body(const EncBlockJob& j, int blk
         __syncthreads();
         STAMP(sbase + 9);
     }
-    if (j.grads_in_lds) add_to_row(row, gacc, gm.psize_blk);
+    if constexpr (GL) add_to_row(row, (const float*)gacc, gm.psize_blk);
     STAMP(sbase + 10);
 }
 
@@ -1631,6 +1645,7 @@ static NarrowJob narrow_job(const sur_encoder_params& p, int blk, int m) {
 #ifndef ENC_BLK_OCC
 #define ENC_BLK_OCC 4   // 128 VGPRs (a few spilled dwords): four workgroups per CU measured best
 #endif
+template <bool GL>     // every wide job keeps its accumulators in LDS (the host clears grads_in_lds of all of them otherwise)
 __global__ void __launch_bounds__(TPB, ENC_BLK_OCC)
 enc_block_bwd_multi_kernel(const EncBlockJob j0, const EncBlockJob j1, const EncBlockJob j2, int njobs, int blk, const NarrowJob nj,
                            int narrow_begin) {
@@ -1640,9 +1655,9 @@ enc_block_bwd_multi_kernel(const EncBlockJob j0, const EncBlockJob j1, const Enc
         enc_narrow_bwd_run(nj, wg - narrow_begin, lds);
         return;
     }
-    if (njobs > 2 && wg >= j2.wg_begin) enc_block_bwd_body(j2, blk, wg - j2.wg_begin, lds);
-    else if (njobs > 1 && wg >= j1.wg_begin) enc_block_bwd_body(j1, blk, wg - j1.wg_begin, lds);
-    else enc_block_bwd_body(j0, blk, wg, lds);
+    if (njobs > 2 && wg >= j2.wg_begin) enc_block_bwd_body<GL>(j2, blk, wg - j2.wg_begin, lds);
+    else if (njobs > 1 && wg >= j1.wg_begin) enc_block_bwd_body<GL>(j1, blk, wg - j1.wg_begin, lds);
+    else enc_block_bwd_body<GL>(j0, blk, wg, lds);
 }
 
 // Encoder forward, one residual block per launch (block 0, 1, 2), several jobs per launch: for large sample counts the
@@ -3232,10 +3247,15 @@ int sur_encoder_backward_multi(void* stream, int njobs, const sur_encoder_params
                 const bool ride = nn > 0;
                 const size_t lds = ride && narrow_lds(narrow[0]) > lds_w ? narrow_lds(narrow[0]) : lds_w;
                 const int grid = grid_w + (ride ? narrow[0].wg_count : 0);
-                if (int rc = set_lds(enc_block_bwd_multi_kernel, lds, "encoder block backward")) return rc;
+                bool all_gl = true;       // LDS accumulators for every wide job, or for none (one instantiation serves the launch)
+                for (int k = 0; k < nw; ++k) all_gl = all_gl && wide[k].grads_in_lds;
+                if (!all_gl)
+                    for (int k = 0; k < nw; ++k) wide[k].grads_in_lds = 0;
+                auto kernel = all_gl ? enc_block_bwd_multi_kernel<true> : enc_block_bwd_multi_kernel<false>;
+                if (int rc = set_lds(kernel, lds, "encoder block backward")) return rc;
                 if (int rc = launch_checked([&] {
-                        hipLaunchKernelGGL(enc_block_bwd_multi_kernel, dim3(grid), dim3(TPB), lds, (hipStream_t)stream, wide[0], wide[1],
-                                           wide[2], nw, blk, narrow[0], ride ? grid_w : grid);
+                        hipLaunchKernelGGL(kernel, dim3(grid), dim3(TPB), lds, (hipStream_t)stream, wide[0], wide[1], wide[2], nw, blk, narrow[0],
+                                           ride ? grid_w : grid);
                     }, "enc_block_bwd")) return rc;
             }
             for (int k = nw ? 1 : 0; k < nn; ++k) {
