@@ -660,6 +660,22 @@ __device__ void lds_load(float* dst, const float* __restrict__ src, int n) {
     for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
     __syncthreads();
 }
+// n4 float4 global -> LDS by LDS-DMA (global_load_lds_dwordx4: one wave instruction moves 64 x 16 B, no VGPRs in between), NOT
+// waited for: any number of these may be in flight; lds_dma_wait() -- or any barrier behind an s_waitcnt vmcnt(0) -- completes
+// them.  dst and src 16-byte aligned.
+__device__ __forceinline__ void lds_dma_v4(float* dst, const float* __restrict__ src, int n4) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int j = wave; j * 64 < n4; j += nw) {
+        const int i4 = j * 64 + lane;
+        if (i4 < n4)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 4 * i4),
+                                             (__attribute__((address_space(3))) void*)(dst + 4 * i4), 16, 0, 0);
+    }
+}
+__device__ __forceinline__ void lds_dma_wait() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
 __device__ void lds_store(float* __restrict__ dst, const float* src, int n) {
     if (dst)
         for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
@@ -1503,11 +1519,14 @@ __device__ __forceinline__ void enc_block_bwd_body(const EncBlockJob& j, int blk
         // this block's input, four of its seven intermediates, the gradient wrt its output.  record: skip | a1pre a1 a2pre | a2 | s | out
         // (one loader with every load of the sample in flight and a single barrier measured 3 % SLOWER on the whole step than
         // these four: 40 more live registers spill in a 128-VGPR kernel, and the co-resident workgroups cover the round trips)
-        if (gm.in_saved_off < 0) lds_load(rb.in, j.x + (size_t)m * nin, nin);
-        else lds_load_v4(rb.in, rec + gm.in_saved_off, nin >> 2);
-        lds_load_v4(rb.a1pre, rec + gm.saved_off + a, (3 * a) >> 2);
-        lds_load_v4(rb.s, rec + gm.saved_off + 5 * a, a >> 2);
-        lds_load_v4(dout, dsrc, a >> 2);
+        // by LDS-DMA: all four in flight at once, one wait + barrier (through registers each was a round trip of its own -- a sixth of
+        // the block's time -- and holding them all in registers spilled; the DMA needs none)
+        if (gm.in_saved_off < 0) lds_dma_v4(rb.in, j.x + (size_t)m * nin, nin >> 2);
+        else lds_dma_v4(rb.in, rec + gm.in_saved_off, nin >> 2);
+        lds_dma_v4(rb.a1pre, rec + gm.saved_off + a, (3 * a) >> 2);
+        lds_dma_v4(rb.s, rec + gm.saved_off + 5 * a, a >> 2);
+        lds_dma_v4(dout, dsrc, a >> 2);
+        lds_dma_wait();
         STAMP(sbase + 2);
         rb_backward(rb, v.w, g, dout, din, g1, g2, g3, xh, sbase + 3, blk > 0);
         if (blk > 0) {

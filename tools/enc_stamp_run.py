@@ -28,7 +28,7 @@ for samples in (64, 256, 1280):
         z = hipops.encode(x, owner.action_enc, owner)
         z.sum().backward()
         torch.cuda.synchronize()
-    buf = (ctypes.c_longlong * 64)()
+    buf = (ctypes.c_longlong * 128)()      # the library copies all 128 slots
     lib.sur_debug_stamps(buf, 0)
     iters = max(1, samples // 256)
     print(f"--- {samples} samples ({iters} per workgroup): cycles (per-sample phases are totals over {iters} iterations)")

@@ -36,7 +36,7 @@ def _fwd_bwd():
 fwd_bwd()
 lib.sur_debug_stamps(None, 1)
 fwd_bwd()
-buf = (ctypes.c_longlong * 32)()
+buf = (ctypes.c_longlong * 128)()      # the library copies all 128 slots
 lib.sur_debug_stamps(buf, 0)
 names = {1: "cell fwd: gates GEMM", 2: "cell fwd: gate activations", 3: "dec fwd: deconv0", 4: "dec fwd: LN0+silu",
          5: "dec fwd: deconv1", 6: "dec fwd: LN1+silu", 7: "dec fwd: conv7", 8: "dec fwd: LN2+silu", 9: "dec fwd: conv5",
@@ -50,3 +50,12 @@ print("(cell phases: 20 executions (2 chunks x 10 steps); decoder phases: the (s
 print(" the first phase of each kernel also contains the time since the previous stamped kernel ended)")
 for i, n in sorted(names.items()):
     print(f"  {n:55s} {vals[i]:9d}")
+print("encoder block backward (enc_block_bwd_multi_kernel, workgroup 0 = first sample of the first wide job = the state encoder;")
+print(" summed over the launches of the step -- one per chunk in the un-forked schedule):")
+phases = ["entry (since the previous stamp: meaningless)", "stage weights, zero the accumulators", "load input / records / dout",
+          "LayerNorm 3 backward", "skip: weight | data gradient", "LayerNorm 2 backward", "conv 2: weight | data gradient",
+          "LayerNorm 1 backward", "conv 1: weight | data gradient", "store din, loop end", "add the accumulators to the partial row"]
+for blk in (2, 1, 0):
+    for k, n in enumerate(phases):
+        if k:
+            print(f"  block {blk}: {n:45s} {vals[64 + 16 * blk + k]:9d}")
