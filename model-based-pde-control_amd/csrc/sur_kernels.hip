@@ -1662,7 +1662,9 @@ static NarrowJob narrow_job(const sur_encoder_params& p, int blk, int m) {
 }
 
 #ifndef ENC_BLK_OCC
-#define ENC_BLK_OCC 4   // 128 VGPRs (a few spilled dwords): four workgroups per CU measured best
+#define ENC_BLK_OCC 3   // 168 VGPRs, no spills.  Four per CU (128 VGPRs, ~30 spilled dwords) measured best while the action encoder's
+                        // 640 samples went through these workgroups too; with those on the narrow path a launch is <= 480 workgroups
+                        // and the spills cost more than the residency gives: 0.496 vs 0.511 ms per step at N = 256 (2 per CU: 0.499)
 #endif
 template <bool GL>     // every wide job keeps its accumulators in LDS (the host clears grads_in_lds of all of them otherwise)
 __global__ void __launch_bounds__(TPB, ENC_BLK_OCC)
