@@ -827,10 +827,11 @@ __device__ void rb_backward(const RBBuf& b, const float* const* w, const GP* g, 
 // The MFMA gather-GEMM path spends its instructions on tile bookkeeping, index functors and masks whatever the channel
 // counts: ~11 k wave-instructions per sample and block backward for ~10 k useful multiply-adds, and these kernels are
 // instruction-issue bound.  Here a lane owns the positions p = lane + 64 e of every channel, keeps
-// its values in registers, reads convolution neighbours from a wave-private LDS copy, reduces LayerNorm statistics and
-// weight gradients with DPP row rotations; the four waves of a workgroup handle four samples independently (no
-// workgroup barrier inside a pass), sharing the staged weights.  Records in `saved`, outputs and partial-gradient rows
-// are laid out exactly as the MFMA path leaves them.
+// its values in registers, reads convolution neighbours from a wave-private LDS copy; LayerNorm statistics of all channels
+// go through one halving butterfly (nr_wave_totals), a convolution's weight gradient is ONE MFMA tile whose reduction
+// dimension is the position (nr_wgrad); the four waves of a workgroup handle four samples independently (no workgroup
+// barrier inside a pass), sharing the staged weights.  Records in `saved`, outputs and partial-gradient rows are laid out
+// exactly as the MFMA path leaves them, so either path can consume the other's.
 // ---------------------------------------------------------------------------------------------
 constexpr int NR_C = 4;   // channels
 // positions per lane: at most 2 (block outputs are <= 128 wide, inputs that need a gradient too: N <= 256)
@@ -1541,9 +1542,11 @@ __device__ __forceinline__ void enc_block_bwd_body(const EncBlockJob& j, int blk
 }
 
 
-// The narrow jobs of a launch set (one wave per sample, see "Narrow residual block") run in kernels of their own, ONE job per
-// launch, with a flat argument block whose arrays are only ever indexed by constants (inside the MFMA kernels the two paths
-// shared one register allocation and the job structs -- indexed by the block number -- went through scratch: 3 KB per lane).
+// A narrow job (one wave per sample, see "Narrow residual block") has a flat argument block whose arrays are only ever indexed
+// by constants (as members of the wide jobs' structs -- indexed by the block number -- they went through scratch: 3 KB per
+// lane).  Its workgroups ride BEHIND the wide jobs' in the same launch (`narrow_begin` of the multi kernels: as launches of
+// their own, serialized behind the wide ones, the narrow kernels lost what they had gained); a launch set without a wide job
+// uses the standalone kernels below.
 struct NarrowJob {
     const float* w[SUR_RB_NPARAM];   // this block's weights (global)
     int size[SUR_RB_NPARAM];
