@@ -515,6 +515,35 @@ def spawn_ranks(n, argv):
     return rc
 
 
+def init_process_group_checked(dist, backend, dev, world, timeout_s=600):
+    """Initialise the process group and PROVE the backend with one checked all-reduce before anything is timed.  The KS path
+    shards envs without a data-path collective, so when RCCL cannot be brought up on this node (driver / IPC mode / two ranks
+    on one device) the measurement does not have to be lost: every rank then re-initialises over gloo, and the line says so
+    (``ranks.requested_backend``, ``ranks.backend_error``) instead of there being no line.  Returns (backend in use, note)."""
+    import datetime
+    timeout = datetime.timedelta(seconds=timeout_s)
+    try:
+        dist.init_process_group(backend, timeout=timeout)
+        cdev = dev if backend == "nccl" else "cpu"
+        x = torch.ones(1, dtype=torch.float64, device=cdev)
+        dist.all_reduce(x, op=dist.ReduceOp.SUM)
+        if backend == "nccl":
+            torch.cuda.synchronize(dev)
+        if int(x.item()) != world:
+            raise RuntimeError(f"all-reduce of ones over {world} ranks returned {x.item()}")
+        return backend, None
+    except Exception as exc:
+        if backend == "gloo":
+            raise
+        note = {"requested_backend": backend, "backend_error": f"{type(exc).__name__}: {str(exc)[:400]}"}
+        try:
+            dist.destroy_process_group()
+        except Exception:
+            pass
+        dist.init_process_group("gloo", timeout=timeout)
+        return "gloo", note
+
+
 def rank_evidence(dist, backend, dev, rank, local_rank, world, elapsed, kernel_ms, K):
     """What the process group itself says about the ranks: one gathered record per rank, a checked all-reduce on the
     backend's own device type, every rank's step time (a straggler shows).  Every rank calls this."""
@@ -585,9 +614,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dist = None
     backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
+    backend_note = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend)
+        backend, backend_note = init_process_group_checked(dist, backend, torch.device("cuda", local_rank), world)
 
     import kspde
     dev = torch.device("cuda", local_rank)
@@ -632,6 +662,8 @@ def main():
         "roofline": roofline_of(args.workload, E, N, kernel_ms, lay),
     }
     if ranks is not None:
+        if backend_note:
+            ranks.update(backend_note)
         out["ranks"] = ranks
     if rank == 0 and n_gpus == 1:
         try:

@@ -58,3 +58,31 @@ def test_two_ranks_started_by_bench_itself():
     import torch
     if torch.cuda.device_count() < 2:
         assert rk["rehearsal"] is True and rk["backend"] == "gloo"
+
+
+@pytest.mark.gpu
+def test_driver_style_launch_survives_a_backend_that_cannot_start():
+    """The driver's own launch line (``python -m torch.distributed.run ... bench.py --gpus 2``, backend left at its default =
+    RCCL) on a box where RCCL cannot form the group -- here: two ranks on ONE device ("Duplicate GPU detected").  The checked
+    first all-reduce fails on every rank, the ranks re-initialise over gloo, the line is still printed and says what happened.
+    (On a node with one GPU per rank the same code path keeps nccl; this is the only RCCL failure a one-GPU box can stage.)"""
+    import socket
+    import subprocess
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs the one-GPU box: with a device per rank RCCL starts")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.pop("BENCH_DIST_BACKEND", None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-tbptt"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rk = json.loads(lines[0])["ranks"]
+    assert rk["backend"] == "gloo" and rk["requested_backend"] == "nccl" and rk["backend_error"], rk
+    assert rk["all_reduce_check"]["ok"] and rk["world_size"] == 2
