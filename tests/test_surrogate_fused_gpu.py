@@ -367,6 +367,35 @@ def test_fused_tbptt_other_chunkings(dev, T):
                 tol=2e-3)   # B = 6 random sequences, both sides fp32 on the GPU: observed <= 3.5e-4 (decoder bias behind a LayerNorm)
 
 
+@pytest.mark.parametrize("N", [64, 256])
+def test_accumulators_in_partial_rows_give_the_same_gradients(dev, N, monkeypatch):
+    """The backward kernels keep their gradient accumulators in LDS when they fit (LDS-typed pointers: the GL = true
+    instantiations of dec_bwd / cell_wgrad / enc_block_bwd) and accumulate straight into the workgroup's partial row otherwise
+    (GL = false).  Every supported geometry fits, so SUR_ACCUMULATE_IN_ROWS=1 forces the second form: the sums are taken in the
+    same order, the gradients must be IDENTICAL."""
+    from pdecontrol.surrogates import ops
+    g = torch.Generator().manual_seed(11)
+    states = (torch.rand(8, 20, 1, N, generator=g) * 2 - 1).to(dev)
+    actions = (torch.rand(8, 20, 1, N, generator=g) * 2 - 1).to(dev)
+    grads, losses = [], []
+    try:
+        ops.enable_fused(True)
+        for force in ("0", "1"):
+            monkeypatch.setenv("SUR_ACCUMULATE_IN_ROWS", force)
+            m = _build(dev, N=N)
+            out = m.training_step((states, actions), 0)
+            out["loss"].backward()
+            torch.cuda.synchronize(dev)
+            grads.append(_grads(m))
+            losses.append(float(out["loss"].detach()))
+    finally:
+        ops.reset_fused()
+    assert losses[0] == losses[1]
+    assert grads[0].keys() == grads[1].keys() and len(grads[0]) > 20
+    for k in grads[0]:
+        assert torch.equal(grads[0][k], grads[1][k]), k
+
+
 def test_fused_training_step_at_a_third_grid_width(dev):
     """N = 128 (between the two benchmark sizes): the shape-specialised primitives -- narrow action-encoder blocks, parity-
     sorted transposed convolutions, single-channel layers as one tile -- at widths 64 / 32 / 128.  Fused step against the
