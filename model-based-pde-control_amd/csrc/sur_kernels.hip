@@ -333,12 +333,19 @@ __device__ void conv_bwd_data(const float* dout, int cout, int hin, const float*
         return;
     }
     const GemmSeg seg[1] = {{W, K, cin * K, dout, hout, cout}};  // A[m=ci][c=o][tap] = W[(o*cin + ci)*K + tap]
+    // stride 2: an input position receives from the taps of one parity only.  As in deconv_fwd the GEMM's columns are the even
+    // positions followed by the odd ones (hin a multiple of 32), so a tile of 16 is of one parity and gemm_taps skips the taps
+    // that reach none of its columns (half of the MFMA steps of the strided block's data gradients).
+    const bool sorted = stride == 2 && (hin & 31) == 0;
+    const int half = hin >> 1;
+    auto pos = [&](int n) { return sorted ? (n < half ? 2 * n : 2 * (n - half) + 1) : n; };
     gemm_taps<K, 1>(ws, sync, cin, hin, seg,
-                    [&](int, int tap, int j) {
-                        const int t = wrapi(j - tap + pad, hin);
+                    [&](int, int tap, int n) {
+                        const int t = wrapi(pos(n) - tap + pad, hin);
                         return (t % stride) ? -1 : t / stride;
                     },
-                    [&](int m, int j, float v) {
+                    [&](int m, int n, float v) {
+                        const int j = pos(n);
                         if (m < cin) din[m * hin + j] = accumulate ? din[m * hin + j] + v : v;
                     });
 }
