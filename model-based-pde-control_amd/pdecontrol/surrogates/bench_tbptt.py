@@ -201,7 +201,8 @@ def run_size(device, N, steps, warmup, B=64, with_plain=True, with_ensemble=True
                                           "(hipops.fused_tbptt_train), combined = every chunk's backward in the same launches; both "
                                           "are captured and timed once per batch shape, the faster one is kept (which hardware "
                                           "queue the graph's second stream gets is the runtime's choice)")
-    res["roofline"] = {"bound": "latency (dependent layer phases, one workgroup per sequence)", "kernels_per_step": 29,
+    res["roofline"] = {"bound": "instruction issue of the two overlapped queues + a critical chain of ~17 dependent launches (not HBM, not MFMA: "
+                                "profiles/r03_tbptt_n256_sq_counters.txt, DESIGN 4.4)", "kernels_per_step": 30,
                        "reference_torch_ops_per_step": "~4 000", "hbm_model_bytes_per_step": bytes_model,
                        "hbm_model_gbs": bytes_model / (ms * 1e-3) / 1e9, "hbm_frac_of_8TBs": bytes_model / (ms * 1e-3) / 8e12}
     # parity of the measured configuration: first-step loss GPU (fused) vs CPU (contract: 1e-5 relative)
